@@ -1,0 +1,14 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the bilevel fine-tune/unlearn step of rezashkv/unlearn-ft.
+
+Pure-torch fp32 restatement of the reference hot path. Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package; the product
+(``unlearn-ft_amd/``) never does and fails loudly when its HIP library is missing.
+
+Parity status: the reference has no tests/golden vectors for this path and its own
+model/trainer modules cannot be imported here (``diffusers``/``torchvision`` absent - ordinary
+ModuleNotFoundError, nothing was denied).  The restatement is therefore pinned sub-block by sub-block
+against the reference pieces that DO import (``oracle/validate_against_reference.py``): compute_snr,
+hard_concrete, gates, and the vendored CompVis ResBlock / SpatialTransformer / Downsample / Upsample /
+timestep_embedding / make_beta_schedule twins; known-answer vectors are committed under tests/golden/.
+"""
+from .config import UNetConfig  # noqa: F401

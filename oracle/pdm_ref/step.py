@@ -1,0 +1,105 @@
+"""Scheduler arithmetic, loss heads and the main / upper training steps (oracle side, fp32 CPU, torch autograd).
+
+  DDIM schedule / add_noise / get_velocity    SURVEY Appendix B.9 (diffusers DDIMScheduler semantics);
+                                               twin: ldm/modules/diffusionmodules/util.py:21-44 (float64)
+  compute_snr                                 pdm/utils/metric_utils.py:3-26
+  step()   (DDPM min-SNR + block + distill)   pdm/training/trainer.py:2403-2488
+  upper_step() (negative-guidance target)     pdm/training/trainer.py:2904-3001
+  AdamW / constant_with_warmup                trainer.py:265-284, 436-443
+"""
+import torch
+import torch.nn.functional as F
+
+from .unet import unet_forward
+
+BLOCK_KEYS = ("d0", "d1", "d2", "d3", "m", "u0", "u1", "u2", "u3")
+
+
+def alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def add_noise(ac, x0, noise, t):
+    a = ac[t].sqrt().view(-1, 1, 1, 1)
+    s = (1.0 - ac[t]).sqrt().view(-1, 1, 1, 1)
+    return a * x0 + s * noise
+
+
+def get_velocity(ac, x0, noise, t):
+    a = ac[t].sqrt().view(-1, 1, 1, 1)
+    s = (1.0 - ac[t]).sqrt().view(-1, 1, 1, 1)
+    return a * noise - s * x0
+
+
+def compute_snr(ac, t):
+    alpha = ac.sqrt()[t].float()
+    sigma = (1.0 - ac).sqrt()[t].float()
+    return (alpha / sigma) ** 2
+
+
+def min_snr_weights(ac, t, gamma=5.0, v_prediction=True):
+    snr = compute_snr(ac, t)
+    if v_prediction:
+        snr = snr + 1
+    return torch.minimum(snr, gamma * torch.ones_like(snr)) / snr
+
+
+def main_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, w_diff=1.0, w_block=0.1, w_dist=2.0, gamma=5.0):
+    """student/teacher = (sd, info).  Returns (loss, diff, dist, block) like trainer.py:2488."""
+    noisy = add_noise(ac, latents, noise, t)
+    target = get_velocity(ac, latents, noise, t)
+    acts_t, acts_s = {}, {}
+    with torch.no_grad():
+        full = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, acts_t)
+    pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
+    w = min_snr_weights(ac, t, gamma)
+    l = F.mse_loss(pred.float(), target.float(), reduction="none")
+    l = (l.mean(dim=(1, 2, 3)) * w).mean()
+    diff = l.detach().clone()
+    loss = l * w_diff
+    block = torch.zeros(())
+    if w_block > 0:
+        for k in BLOCK_KEYS:
+            block = block + F.mse_loss(acts_s[k], acts_t[k].detach())
+        block = block / len(BLOCK_KEYS)
+        loss = loss + w_block * block
+    dist = torch.zeros(())
+    if w_dist > 0:
+        dist = F.mse_loss(pred.float(), full.float())
+        loss = loss + w_dist * dist
+    return loss, diff, dist.detach(), block.detach(), pred
+
+
+def upper_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, empty_ehs, w_dist=1.0, w_block=0.0):
+    noisy = add_noise(ac, latents, noise, t)
+    acts_t, acts_s = {}, {}
+    with torch.no_grad():
+        e_c = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, acts_t)
+        e_u = unet_forward(teacher[0], cfg, teacher[1], noisy, t, empty_ehs, {})
+    # NB the reference's block hooks hold the LAST teacher call (uncond) - irrelevant while upper block weight = 0
+    pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
+    loss = torch.zeros(())
+    block = torch.zeros(())
+    dist = F.mse_loss(pred, e_u - (e_c - e_u))
+    loss = loss + w_dist * dist
+    return loss, torch.zeros(()), dist.detach(), block, pred
+
+
+def adamw_step(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias-corrected), in place; step is 1-based."""
+    for k in params:
+        g = grads[k]
+        p = params[k]
+        p.mul_(1 - lr * wd)
+        m[k].mul_(b1).add_(g, alpha=1 - b1)
+        v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** step
+        bc2 = 1 - b2 ** step
+        denom = (v[k].sqrt() / (bc2 ** 0.5)).add_(eps)
+        p.addcdiv_(m[k], denom, value=-lr / bc1)
+
+
+def constant_with_warmup(base_lr, k, warmup):
+    """lr after k scheduler steps (k counts scheduler.step() calls; accelerate steps it W times per optimiser step)."""
+    return base_lr * min(1.0, k / max(1, warmup)) if warmup > 0 else base_lr
