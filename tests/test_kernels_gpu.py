@@ -1,0 +1,362 @@
+"""Kernel-level parity (-m gpu): every libpdmk entry point, called through the C ABI, against a plain fp32 torch
+statement of the same op on identical inputs.  Tolerances: fp32 path 2e-4 of the output scale (MFMA fp32 is an exact
+fmaf chain; only summation order differs); bf16 path 2e-2 of the output scale against fp32 math on the bf16-rounded
+inputs (bf16 storage of outputs/intermediates, fp32 accumulation)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f32": 2e-4, "bf16": 2e-2}
+
+
+def close(got, ref, tol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def rnd(shape, dev, dtype, scale=1.0):
+    return (torch.randn(*shape, device=dev) * scale).to(dtype)
+
+
+def conv_w_pack(w):   # [Co,Ci,3,3] -> [Co, 9*Ci]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (128, 128, 32), (1, 8, 8), (515, 320, 1024)])
+def test_gemm_linear(dev, dn, M, N, K):
+    from pdm import _pdmk as k
+    torch.manual_seed(0)
+    dt = DT[dn]
+    A, B = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5)
+    bias = torch.randn(N, device=dev)
+    nb = 1 if M < 5 else 5
+    rows_per_b = (M + nb - 1) // nb
+    rv = torch.randn(nb, N, device=dev)
+    R = rnd((M, N), dev, dt)
+    C = torch.zeros(M, N, device=dev, dtype=dt)
+    k.gemm(A, B, C, M, N, K, K, K, N, bias=bias, rowvec=rv, rows_per_b=rows_per_b, R=R, ldr=N)
+    ref = A.float() @ B.float().t() + bias + rv[torch.arange(M, device=dev) // rows_per_b] + R.float()
+    close(C, ref, TOL[dn], "gemm+epilogue")
+    C2 = C.clone()
+    k.gemm(A, B, C2, M, N, K, K, K, N, accumulate=True, alpha=0.5)
+    close(C2, C.float() + 0.5 * (A.float() @ B.float().t()), TOL[dn], "gemm accumulate")
+    Cf = torch.zeros(M, N, device=dev)
+    k.gemm(A, B, Cf, M, N, K, K, K, N, out_f32=True)
+    close(Cf, A.float() @ B.float().t(), TOL[dn], "gemm out_f32")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_gemm_conv_fwd_modes(dev, dn, mode):
+    from pdm import _pdmk as k
+    torch.manual_seed(1)
+    dt = DT[dn]
+    Bn, Ci, Co, Hs = 2, 24, 40, 10
+    x = rnd((Bn, Hs, Hs, Ci), dev, dt)          # NHWC source
+    w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
+    xn = x.float().permute(0, 3, 1, 2)
+    if mode == 0:
+        ref = F.conv2d(xn, w.float(), padding=1)
+    elif mode == 1:
+        ref = F.conv2d(xn, w.float(), stride=2, padding=1)
+    elif mode == 2:
+        ref = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode="nearest"), w.float(), padding=1)
+    else:   # transposed stride 2 with the same (un-flipped) taps: y[v] = sum_t x[(v+t-1)/2] w[t]
+        up = torch.zeros(Bn, Ci, 2 * Hs, 2 * Hs, device=dev)
+        up[:, :, ::2, ::2] = xn
+        ref = F.conv2d(up, w.float(), padding=1)
+    Ho = ref.shape[2]
+    M = Bn * Ho * Ho
+    C = torch.zeros(M, Co, device=dev, dtype=dt)
+    k.gemm(x, conv_w_pack(w), C, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV,
+           conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci))
+    close(C.view(Bn, Ho, Ho, Co), ref.permute(0, 2, 3, 1), TOL[dn], f"conv mode {mode}")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_gemm_wgrad_linear(dev, dn, splitk):
+    from pdm import _pdmk as k
+    torch.manual_seed(2)
+    dt = DT[dn]
+    P, No, Ki = 300, 72, 136            # P pixels (reduction), dW [No, Ki]
+    dY, X = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
+    dW = torch.zeros(No, Ki, device=dev)
+    k.gemm(dY, X, dW, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=splitk)
+    close(dW, dY.float().t() @ X.float(), TOL[dn], "wgrad linear")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_gemm_wgrad_conv(dev, dn, mode):
+    from pdm import _pdmk as k
+    torch.manual_seed(3)
+    dt = DT[dn]
+    Bn, Ci, Co, Hs = 2, 16, 24, 8
+    x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+    xn = x.float().permute(0, 3, 1, 2).requires_grad_(False)
+    w = torch.zeros(Co, Ci, 3, 3, device=dev, requires_grad=True)
+    if mode == 0:
+        y = F.conv2d(xn, w, padding=1)
+    elif mode == 1:
+        y = F.conv2d(xn, w, stride=2, padding=1)
+    else:
+        y = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode="nearest"), w, padding=1)
+    Ho = y.shape[2]
+    dy = rnd((Bn, Ho, Ho, Co), dev, dt)
+    (gw,) = torch.autograd.grad(y, w, dy.float().permute(0, 3, 1, 2))
+    P = Bn * Ho * Ho
+    dW = torch.zeros(Co, 9 * Ci, device=dev)
+    k.gemm(dy, x, dW, Co, 9 * Ci, P, Co, 0, 9 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=2,
+           conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci))
+    close(dW, conv_w_pack(gw), TOL[dn], f"wgrad conv mode {mode}")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_conv_dgrad_via_cast_permute(dev, dn):
+    from pdm import _pdmk as k
+    torch.manual_seed(4)
+    dt = DT[dn]
+    Bn, Ci, Co, Hs = 2, 16, 24, 8
+    w = torch.randn(Co, Ci, 3, 3, device=dev) * (9 * Ci) ** -0.5
+    wp = conv_w_pack(w)                                   # fp32 master layout [Co, 9, Ci]
+    wd = torch.zeros(Ci, 9 * Co, device=dev, dtype=dt)
+    k.cast_permute(wp, wd, Co, 9, Ci, 2)
+    wq = wp.to(dt).float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2)    # the rounded weights, OIHW
+    for stride, mode in ((1, 0), (2, 3)):
+        xn = torch.randn(Bn, Ci, Hs, Hs, device=dev, requires_grad=True)
+        y = F.conv2d(xn, wq, stride=stride, padding=1)
+        Hy = y.shape[2]
+        dy = rnd((Bn, Hy, Hy, Co), dev, dt)
+        (gx,) = torch.autograd.grad(y, xn, dy.float().permute(0, 3, 1, 2))
+        M = Bn * Hs * Hs
+        dX = torch.zeros(M, Ci, device=dev, dtype=dt)
+        k.gemm(dy, wd, dX, M, Ci, 9 * Co, 0, 9 * Co, Ci, a_mode=k.A_CONV, conv=(Bn, Hy, Hy, Co, Hs, Hs, mode, Co))
+        close(dX.view(Bn, Hs, Hs, Ci), gx.permute(0, 2, 3, 1), TOL[dn], f"conv dgrad stride {stride}")
+    # Linear transpose copy
+    W = torch.randn(40, 24, device=dev)
+    Wt = torch.zeros(24, 40, device=dev, dtype=dt)
+    k.cast_permute(W, Wt, 40, 1, 24, 1)
+    close(Wt, W.t().to(dt), 0, "cast_permute transpose")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("C,G,gs,HW,silu", [(64, 32, 2, 256, True), (40, 17, 2, 64, True), (320, 32, 10, 1024, False),
+                                            (2560, 32, 80, 64, True), (176, 17, 10, 4, True)])
+def test_groupnorm(dev, dn, C, G, gs, HW, silu):
+    from pdm import _pdmk as k
+    torch.manual_seed(5)
+    dt = DT[dn]
+    Bn, cr = 3, G * gs
+    x = rnd((Bn, HW, C), dev, dt) + 0.5
+    gamma, beta = torch.randn(cr, device=dev) * 0.3 + 1, torch.randn(cr, device=dev) * 0.3
+    y = torch.full((Bn, HW, C), 7.0, device=dev, dtype=dt)
+    stats = torch.zeros(Bn, G, 2, device=dev)
+    ws = torch.zeros(Bn * G * 2, device=dev, dtype=torch.float64)
+    k.groupnorm_fwd(x, y, gamma, beta, stats, ws, Bn, HW, C, C, C, G, gs, 1e-5, silu)
+    xr = x.float()[..., :cr].permute(0, 2, 1).clone().requires_grad_(True)      # [B, cr, HW]
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.group_norm(xr, G, gr, br, 1e-5)
+    ref = F.silu(z) if silu else z
+    close(y[..., :cr], ref.permute(0, 2, 1), TOL[dn], "gn fwd")
+    assert (y[..., cr:] == 0).all()
+    dy = rnd((Bn, HW, C), dev, dt)
+    gx, gg, gb = torch.autograd.grad(ref, [xr, gr, br], dy.float()[..., :cr].permute(0, 2, 1))
+    dx = torch.zeros_like(x)
+    dgm, dbt = torch.zeros(cr, device=dev), torch.zeros(cr, device=dev)
+    k.groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgm, dbt, ws, Bn, HW, C, C, C, C, G, gs, silu, False)
+    close(dx[..., :cr], gx.permute(0, 2, 1), TOL[dn] * 2, "gn dx")
+    close(dgm, gg, TOL[dn] * 2, "gn dgamma")
+    close(dbt, gb, TOL[dn] * 2, "gn dbeta")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("C,M", [(64, 37), (320, 300), (1280, 64)])
+def test_layernorm(dev, dn, C, M):
+    from pdm import _pdmk as k
+    torch.manual_seed(6)
+    dt = DT[dn]
+    x = rnd((M, C), dev, dt) + 0.3
+    gamma, beta = torch.randn(C, device=dev) * 0.3 + 1, torch.randn(C, device=dev) * 0.3
+    y = torch.zeros_like(x)
+    stats = torch.zeros(M, 2, device=dev)
+    k.layernorm_fwd(x, y, gamma, beta, stats, M, C, C, C, 1e-5)
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    close(y, ref, TOL[dn], "ln fwd")
+    dy = rnd((M, C), dev, dt)
+    gx, gg, gb = torch.autograd.grad(ref, [xr, gr, br], dy.float())
+    dx = torch.zeros_like(x)
+    dgm, dbt = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    k.layernorm_bwd(x, dy, dx, gamma, stats, dgm, dbt, M, C, C, C, C, False)
+    close(dx, gx, TOL[dn] * 2, "ln dx")
+    close(dgm, gg, TOL[dn] * 2, "ln dgamma")
+    close(dbt, gb, TOL[dn] * 2, "ln dbeta")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("Nq,Nk,H", [(100, 100, 3), (64, 77, 2), (4, 4, 1), (256, 13, 5)])
+def test_attention(dev, dn, Nq, Nk, H):
+    from pdm import _pdmk as k
+    torch.manual_seed(7)
+    dt = DT[dn]
+    Bn, D = 2, 64
+    self_attn = Nq == Nk
+    # fused projections output layout: q|k|v side by side in one row when self-attention
+    if self_attn:
+        qkv = rnd((Bn, Nq, 3 * H * D), dev, dt)
+        q, kk, v = qkv[..., :H * D], qkv[..., H * D:2 * H * D], qkv[..., 2 * H * D:]
+        qs = ks = vs = (Nq * 3 * H * D, 3 * H * D)
+    else:
+        q = rnd((Bn, Nq, H * D), dev, dt)
+        kv = rnd((Bn, Nk, 2 * H * D), dev, dt)
+        kk, v = kv[..., :H * D], kv[..., H * D:]
+        qs, ks, vs = (Nq * H * D, H * D), (Nk * 2 * H * D, 2 * H * D), (Nk * 2 * H * D, 2 * H * D)
+    o = torch.zeros(Bn, Nq, H * D, device=dev, dtype=dt)
+    lse = torch.zeros(Bn, H, Nq, device=dev)
+    os_ = (Nq * H * D, H * D)
+    scale = D ** -0.5
+    k.attn_fwd(q, kk, v, o, lse, Bn, H, Nq, Nk, qs, ks, vs, os_, scale)
+    qr = q.float().reshape(Bn, Nq, H, D).transpose(1, 2).clone().requires_grad_(True)
+    kr = kk.float().reshape(Bn, Nk, H, D).transpose(1, 2).clone().requires_grad_(True)
+    vr = v.float().reshape(Bn, Nk, H, D).transpose(1, 2).clone().requires_grad_(True)
+    s = (qr @ kr.transpose(-1, -2)) * scale
+    ref = torch.softmax(s, -1) @ vr
+    close(o.view(Bn, Nq, H, D).transpose(1, 2), ref, TOL[dn], "attn fwd")
+    close(lse * math.log(2.0), torch.logsumexp(s, -1), TOL[dn], "attn lse")
+    do = rnd((Bn, Nq, H * D), dev, dt)
+    gq, gk, gv = torch.autograd.grad(ref, [qr, kr, vr], do.float().view(Bn, Nq, H, D).transpose(1, 2))
+    dq = torch.zeros(Bn, Nq, H * D, device=dev, dtype=dt)
+    dk = torch.zeros(Bn, Nk, H * D, device=dev, dtype=dt)
+    dv = torch.zeros(Bn, Nk, H * D, device=dev, dtype=dt)
+    delta = torch.zeros(Bn, H, Nq, device=dev)
+    k.attn_bwd(q, kk, v, o, do, lse, delta, dq, dk, dv, Bn, H, Nq, Nk, qs, ks, vs, os_, os_, (Nk * H * D, H * D),
+               (Nk * H * D, H * D), scale)
+    close(dq.view(Bn, Nq, H, D).transpose(1, 2), gq, TOL[dn] * 2, "attn dq")
+    close(dk.view(Bn, Nk, H, D).transpose(1, 2), gk, TOL[dn] * 2, "attn dk")
+    close(dv.view(Bn, Nk, H, D).transpose(1, 2), gv, TOL[dn] * 2, "attn dv")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_elementwise_family(dev, dn):
+    from pdm import _pdmk as k
+    torch.manual_seed(8)
+    dt = DT[dn]
+    tol = TOL[dn]
+    # GEGLU
+    M, Fd = 50, 120
+    x = rnd((M, 2 * Fd), dev, dt)
+    y = torch.zeros(M, Fd, device=dev, dtype=dt)
+    k.geglu_fwd(x, y, M, Fd, 2 * Fd, Fd)
+    xr = x.float().requires_grad_(True)
+    ref = xr[:, :Fd] * F.gelu(xr[:, Fd:])
+    close(y, ref, tol, "geglu fwd")
+    dy = rnd((M, Fd), dev, dt)
+    (gx,) = torch.autograd.grad(ref, xr, dy.float())
+    dx = torch.zeros_like(x)
+    k.geglu_bwd(x, dy, dx, M, Fd, 2 * Fd, Fd, 2 * Fd)
+    close(dx, gx, tol, "geglu bwd")
+    # SiLU
+    t = rnd((3, 1280), dev, dt)
+    st = torch.zeros_like(t)
+    k.silu_fwd(t, st)
+    tr = t.float().requires_grad_(True)
+    close(st, F.silu(tr), tol, "silu")
+    dyt = rnd((3, 1280), dev, dt)
+    dxt = torch.zeros_like(t)
+    k.silu_bwd(t, dyt, dxt)
+    close(dxt, torch.autograd.grad(F.silu(tr), tr, dyt.float())[0], tol, "silu bwd")
+    # copy2d into / out of a concat buffer, accumulate
+    a, b = rnd((20, 24), dev, dt), rnd((20, 40), dev, dt)
+    cat = torch.zeros(20, 64, device=dev, dtype=dt)
+    k.copy2d(a, cat, 20, 24, 24, 64)
+    k.copy2d(b, cat[:, 24:], 20, 40, 40, 64)
+    assert torch.equal(cat, torch.cat([a, b], 1))
+    k.copy2d(b, cat[:, 24:], 20, 40, 40, 64, accumulate=True)
+    close(cat[:, 24:], 2 * b.float(), tol, "copy2d acc")
+    # colsum
+    xs = rnd((333, 48), dev, dt)
+    cs = torch.zeros(48, device=dev)
+    k.colsum(xs, cs, 333, 48, 48)
+    close(cs, xs.float().sum(0), tol, "colsum")
+    # pool
+    src = rnd((2, 8, 8, 16), dev, dt)
+    dst = torch.zeros(2, 4, 4, 16, device=dev, dtype=dt)
+    k.pool2x2_sum(src, dst, 2, 4, 4, 16)
+    close(dst, F.avg_pool2d(src.float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1) * 4, tol, "pool")
+    # axpby
+    xa, ya = rnd((1000,), dev, dt), rnd((1000,), dev, dt)
+    r = 2.0 * xa.float() - 1.0 * ya.float()
+    k.axpby(xa, ya, 2.0, -1.0)
+    close(ya, r, tol, "axpby")
+
+
+def test_scalar_kernels(dev):
+    from pdm import _pdmk as k
+    import numpy as np, os
+    torch.manual_seed(9)
+    # timestep embedding against the reference's CompVis twin (golden fixture)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_twins.npz"))
+    t = torch.from_numpy(gold["temb_t"]).to(dev)
+    out = torch.zeros(len(t), 320, device=dev)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(160, dtype=torch.float32) / 160).to(dev)
+    k.timestep_embed(t, freqs, out, len(t), 320)
+    close(out, torch.from_numpy(gold["temb_ref"]).to(dev), 2e-5, "timestep_embed vs ldm twin")
+    # forward diffusion
+    Bn, Cc, HW = 3, 4, 64
+    x0, nz = torch.randn(Bn, Cc, HW, device=dev), torch.randn(Bn, Cc, HW, device=dev)
+    ts = torch.tensor([0, 500, 999], device=dev)
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000) ** 2
+    ac = torch.cumprod(1 - betas, 0).to(dev)
+    sa, sb = ac.sqrt().contiguous(), (1 - ac).sqrt().contiguous()
+    noisy = torch.zeros(Bn, HW, 8, device=dev)
+    target = torch.zeros(Bn, HW, 8, device=dev)
+    k.add_noise_velocity(x0, nz, ts, sa, sb, noisy, target, Bn, Cc, HW, 8)
+    a, s = sa[ts].view(-1, 1, 1), sb[ts].view(-1, 1, 1)
+    close(noisy[..., :4], (a * x0 + s * nz).permute(0, 2, 1), 1e-6, "add_noise")
+    close(target[..., :4], (a * nz - s * x0).permute(0, 2, 1), 1e-6, "velocity")
+    assert (noisy[..., 4:] == 0).all()
+    back = torch.zeros(Bn, Cc, HW, device=dev)
+    k.nhwc_to_nchw(noisy, back, Bn, Cc, HW, 8)
+    close(back, a * x0 + s * nz, 1e-6, "nhwc_to_nchw")
+    nh = torch.zeros(Bn, HW, 8, device=dev, dtype=torch.bfloat16)
+    k.nchw_to_nhwc(x0, nh, Bn, Cc, HW, 8)
+    close(nh[..., :4], x0.permute(0, 2, 1).bfloat16(), 0, "nchw_to_nhwc")
+    # mse fwd/bwd with per-sample weights, mixed dtypes
+    pa = torch.randn(Bn, 100, 8, device=dev).bfloat16()
+    pb = torch.randn(Bn, 100, 8, device=dev)
+    w = torch.rand(Bn, device=dev)
+    out = torch.zeros(4, device=dev, dtype=torch.float64)
+    k.mse_fwd(pa, pb, w, out, 2, Bn, 100, 4, 8, 8, 1.0 / (Bn * 400))
+    ref = (((pa.float()[..., :4] - pb[..., :4]) ** 2).mean(dim=(1, 2)) * w).mean()
+    close(out[2:3], ref.view(1), 1e-5, "mse fwd")
+    da = torch.zeros_like(pa)
+    k.mse_bwd(pa, pb, w, da, Bn, 100, 4, 8, 8, 8, 0.37, False)
+    close(da[..., :4], 0.37 * w.view(-1, 1, 1) * (pa.float()[..., :4] - pb[..., :4]), 1e-2, "mse bwd")
+    # AdamW against torch.optim.AdamW over 3 steps
+    n = 1024 * 4 + 8
+    p0 = torch.randn(n, device=dev)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    lr = torch.tensor([1e-3], device=dev)
+    for stp in range(1, 4):
+        g = torch.randn(n, device=dev)
+        pt.grad = g.clone()
+        opt.step()
+        bc = torch.tensor([1 - 0.9 ** stp, 1 - 0.999 ** stp], device=dev)
+        gg = g.clone()
+        k.adamw(p, gg, m, v, n, lr, 0.9, 0.999, 1e-8, 0.01, bc, 1.0, True)
+        assert (gg == 0).all()
+    close(p, pt.detach(), 1e-6, "adamw")
+    ss = torch.zeros(2, device=dev, dtype=torch.float64)
+    k.sumsq(p0, n, ss, 1)
+    close(ss[1:2], (p0.double() ** 2).sum().view(1), 1e-6, "sumsq")

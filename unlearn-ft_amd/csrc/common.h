@@ -1,0 +1,106 @@
+// pdmk — gfx950 (MI355X / CDNA4) kernel library for the pruned SD-2.1 U-Net bilevel training step.
+// Shared device helpers: MFMA fragment traits for bf16 (16x16x32) and exact-f32 (16x16x4) paths, wave reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pdmk.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define PDMK_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return -(1000 + (int)e__);     \
+    } while (0)
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA traits.  A 16x16 output tile per instruction; lane l: C[row=(l>>4)*4+r][col=l&15], r=0..3.
+//   bf16: v_mfma_f32_16x16x32_bf16, lane l holds A[row l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][col l&15], j=0..7
+//   f32 : v_mfma_f32_16x16x4_f32  , lane l holds A[row l&15][k=l>>4],       B[k=l>>4][col l&15]      (exact fp32)
+// LDS tiles come in two layouts:
+//   "rowk": element (row,k) at lds[row*rs+k]   (k contiguous)       -> ds_read_b128 / ds_read_b32
+//   "colk": element (k,col) at lds[k*rs+col]   (reduction-major)    -> ds_read_b64_tr_b16 (bf16) / ds_read_b32
+// ---------------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16> {
+    static constexpr int KS = 32;   // k per instruction
+    static constexpr int CH = 8;    // elements per 16-byte chunk
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ frag load_rowk(const bf16* lds, int rs, int row0, int k0, int lane) {
+        return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * rs + k0 + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ frag load_colk(const bf16* lds, int rs, int k0, int col0, int lane) {
+        // two transposed 4(k) x 16(col) block reads; EXEC must be all ones here (no divergence around this call)
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const bf16* a0 = lds + (k0 + 8 * g + q) * rs + col0 + 4 * p;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * rs));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <> struct Mma<float> {
+    static constexpr int KS = 4;
+    static constexpr int CH = 4;
+    typedef float frag;
+    static __device__ __forceinline__ frag load_rowk(const float* lds, int rs, int row0, int k0, int lane) {
+        return lds[(row0 + (lane & 15)) * rs + k0 + (lane >> 4)];
+    }
+    static __device__ __forceinline__ frag load_colk(const float* lds, int rs, int k0, int col0, int lane) {
+        return lds[(k0 + (lane >> 4)) * rs + col0 + (lane & 15)];
+    }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (private L2); give each XCD a
+// contiguous run of logical tiles so neighbouring tiles (shared operand panels) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    const float s = 1.0f / (1.0f + expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+}

@@ -1,0 +1,508 @@
+// Bandwidth-bound elementwise / reduction kernels of the step: GEGLU, SiLU, strided copies (skip concat), weight
+// cast/permute, bias-gradient column sums, 2x2 sum-pool (upsample bwd), timestep embedding, forward diffusion,
+// layout converters, loss heads, AXPBY, fused AdamW.  All bulk traffic moves as 16-byte chunks per lane.
+#include "common.h"
+#include "vec.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int grid_for(long nwork, int cap = 4096) { return (int)max(1L, min((long)cap, (nwork + NT - 1) / NT)); }
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+template <typename T>
+__global__ void geglu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long M, int F, int ldx, int ldy) {
+    constexpr int V = Vec<T>::N;
+    const int fc = F / V;
+    const long total = M * fc;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long m = i / fc;
+        const int c = (int)(i - m * fc) * V;
+        float h[V], g[V];
+        Vec<T>::load(x + m * ldx + c, h);
+        Vec<T>::load(x + m * ldx + F + c, g);
+#pragma unroll
+        for (int e = 0; e < V; ++e) h[e] *= gelu_f(g[e]);
+        Vec<T>::store(y + m * ldy + c, h);
+    }
+}
+template <typename T>
+__global__ void geglu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long M, int F,
+                                 int ldx, int lddy, int lddx) {
+    constexpr int V = Vec<T>::N;
+    const int fc = F / V;
+    const long total = M * fc;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long m = i / fc;
+        const int c = (int)(i - m * fc) * V;
+        float h[V], g[V], d[V], dh[V], dg[V];
+        Vec<T>::load(x + m * ldx + c, h);
+        Vec<T>::load(x + m * ldx + F + c, g);
+        Vec<T>::load(dy + m * lddy + c, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            dh[e] = d[e] * gelu_f(g[e]);
+            dg[e] = d[e] * h[e] * gelu_grad_f(g[e]);
+        }
+        Vec<T>::store(dx + m * lddx + c, dh);
+        Vec<T>::store(dx + m * lddx + F + c, dg);
+    }
+}
+template <typename T> int geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (F % V || ldx % V || ldy % V) return -1;
+    hipLaunchKernelGGL(geglu_fwd_kernel<T>, dim3(grid_for((long)M * F / V)), dim3(NT), 0, st, (const T*)x, (T*)y,
+                       (long)M, F, ldx, ldy);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T>
+int geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (F % V || ldx % V || lddy % V || lddx % V) return -1;
+    hipLaunchKernelGGL(geglu_bwd_kernel<T>, dim3(grid_for((long)M * F / V)), dim3(NT), 0, st, (const T*)x,
+                       (const T*)dy, (T*)dx, (long)M, F, ldx, lddy, lddx);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ SiLU / AXPBY
+template <typename T, int OP>   // 0 silu fwd, 1 silu bwd (y=dy in, out=dx), 2 axpby
+__global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* __restrict__ y, long n, float alpha,
+                          float beta) {
+    constexpr int V = Vec<T>::N;
+    const long nv = n / V;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < nv; i += (long)gridDim.x * NT) {
+        float f[V], o[V];
+        Vec<T>::load(x + i * V, f);
+        if (OP == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = silu_f(f[e]);
+        } else if (OP == 1) {
+            Vec<T>::load(a + i * V, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] *= silu_grad_f(f[e]);
+        } else {
+            Vec<T>::load(y + i * V, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = alpha * f[e] + beta * o[e];
+        }
+        Vec<T>::store(y + i * V, o);
+    }
+    // scalar tail
+    for (long i = nv * V + blockIdx.x * (long)NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const float f = to_f32(x[i]);
+        float o;
+        if (OP == 0) o = silu_f(f);
+        else if (OP == 1) o = to_f32(a[i]) * silu_grad_f(f);
+        else o = alpha * f + beta * to_f32(y[i]);
+        y[i] = from_f32<T>(o);
+    }
+}
+template <typename T, int OP>
+int ew(const void* x, const void* a, void* y, long n, float alpha, float beta, hipStream_t st) {
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)a) & 15) return -1;
+    hipLaunchKernelGGL((ew_kernel<T, OP>), dim3(grid_for(n / Vec<T>::N + 1)), dim3(NT), 0, st, (const T*)x,
+                       (const T*)a, (T*)y, n, alpha, beta);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ copy2d
+template <typename T>
+__global__ void copy2d_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, int cols, int lds, int ldd,
+                              int acc) {
+    constexpr int V = Vec<T>::N;
+    const int cc = cols / V;
+    const long total = rows * cc;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / cc;
+        const int c = (int)(i - r * cc) * V;
+        float f[V];
+        Vec<T>::load(src + r * lds + c, f);
+        if (acc) {
+            float o[V];
+            Vec<T>::load(dst + r * ldd + c, o);
+#pragma unroll
+            for (int e = 0; e < V; ++e) f[e] += o[e];
+        }
+        Vec<T>::store(dst + r * ldd + c, f);
+    }
+}
+template <typename T>
+int copy2d(const void* src, void* dst, long rows, int cols, int lds, int ldd, int acc, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (cols % V || lds % V || ldd % V || (((uintptr_t)src | (uintptr_t)dst) & 15)) return -1;
+    hipLaunchKernelGGL(copy2d_kernel<T>, dim3(grid_for(rows * cols / V)), dim3(NT), 0, st, (const T*)src, (T*)dst,
+                       rows, cols, lds, ldd, acc);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ cast / permute
+// mode 0: dst[i] = src[i];  mode 1: [n0,n2] -> [n2,n0];  mode 2: conv [n0=Co,9,n2=Ci] -> [Ci, 9 (flipped), Co]
+template <typename T>
+__global__ void cast_permute_kernel(const float* __restrict__ src, T* __restrict__ dst, int n0, int n1, int n2,
+                                    int mode) {
+    const long total = (long)n0 * n1 * n2;
+    for (long o = blockIdx.x * (long)NT + threadIdx.x; o < total; o += (long)gridDim.x * NT) {
+        long s;
+        if (mode == 0) {
+            s = o;
+        } else if (mode == 1) {   // o = i2*n0 + i0
+            const long i2 = o / n0, i0 = o - i2 * n0;
+            s = i0 * n2 + i2;
+        } else {                  // o = (i2*9 + t')*n0 + i0,  t = 8 - t'
+            const long i0 = o % n0, rest = o / n0;
+            const long tp = rest % n1, i2 = rest / n1;
+            s = (i0 * n1 + (n1 - 1 - tp)) * n2 + i2;
+        }
+        dst[o] = from_f32<T>(src[s]);
+    }
+}
+template <typename T> int cast_permute(const float* src, void* dst, int n0, int n1, int n2, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(cast_permute_kernel<T>, dim3(grid_for((long)n0 * n1 * n2, 8192)), dim3(NT), 0, st, src, (T*)dst,
+                       n0, n1, n2, mode);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ colsum
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, int ld,
+                              long rows_per_blk) {
+    constexpr int V = Vec<T>::N;
+    const int nc = N / V;
+    const long r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+    for (int c = blockIdx.x * NT + threadIdx.x; c < nc; c += gridDim.x * NT) {
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
+        for (long r = r0; r < r1; ++r) {
+            float f[V];
+            Vec<T>::load(x + r * ld + c * V, f);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[c * V + e], s[e]);
+    }
+}
+template <typename T> int colsum(const void* x, float* out, long M, int N, int ld, int acc, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (N % V || ld % V) return -1;
+    if (!acc && hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) return -1000;
+    const int gx = (N / V + NT - 1) / NT;
+    const int gy = (int)max(1L, min(M, 2048L / gx));
+    const long rpb = (M + gy - 1) / gy;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (int)((M + rpb - 1) / rpb)), dim3(NT), 0, st, (const T*)x, out, M, N,
+                       ld, rpb);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ 2x2 sum pool
+template <typename T>
+__global__ void pool_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C) {
+    constexpr int V = Vec<T>::N;
+    const int cc = C / V;
+    const long total = (long)B * H * W * cc;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % cc) * V;
+        long p = i / cc;
+        const int xw = (int)(p % W); p /= W;
+        const int yh = (int)(p % H);
+        const long b = p / H;
+        const T* s = src + ((b * 2 * H + 2 * yh) * 2 * W + 2 * xw) * (long)C + c;
+        float a[V], t[V];
+        Vec<T>::load(s, a);
+        Vec<T>::load(s + C, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += t[e];
+        Vec<T>::load(s + 2L * W * C, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += t[e];
+        Vec<T>::load(s + 2L * W * C + C, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += t[e];
+        Vec<T>::store(dst + ((b * H + yh) * W + xw) * (long)C + c, a);
+    }
+}
+template <typename T> int pool(const void* src, void* dst, int B, int H, int W, int C, hipStream_t st) {
+    if (C % Vec<T>::N) return -1;
+    hipLaunchKernelGGL(pool_kernel<T>, dim3(grid_for((long)B * H * W * C / Vec<T>::N)), dim3(NT), 0, st, (const T*)src,
+                       (T*)dst, B, H, W, C);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ timestep embedding
+template <typename T>
+__global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, T* __restrict__ out, int B,
+                            int dim) {
+    const int half = dim / 2;
+    const int total = B * half;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < total; i += gridDim.x * NT) {
+        const int b = i / half, j = i - b * half;
+        const float arg = (float)t[b] * freqs[j];
+        out[(long)b * dim + j] = from_f32<T>(cosf(arg));
+        out[(long)b * dim + half + j] = from_f32<T>(sinf(arg));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward diffusion
+template <typename T>
+__global__ void noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                             const int64_t* __restrict__ t, const float* __restrict__ sa, const float* __restrict__ sb,
+                             T* __restrict__ noisy, float* __restrict__ target, int B, int C, int HW, int cpad) {
+    const long total = (long)B * HW * cpad;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % cpad);
+        const long p = i / cpad;
+        const int px = (int)(p % HW);
+        const int b = (int)(p / HW);
+        float xn = 0.f, v = 0.f;
+        if (c < C) {
+            const long s = ((long)b * C + c) * HW + px;
+            const float a = sa[t[b]], sg = sb[t[b]];
+            xn = a * x0[s] + sg * noise[s];
+            v = a * noise[s] - sg * x0[s];
+        }
+        noisy[i] = from_f32<T>(xn);
+        if (target) target[i] = v;
+    }
+}
+template <typename T>
+__global__ void nchw2nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW, int cpad) {
+    const long total = (long)B * HW * cpad;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % cpad);
+        const long p = i / cpad;
+        const int px = (int)(p % HW);
+        const int b = (int)(p / HW);
+        dst[i] = from_f32<T>(c < C ? src[((long)b * C + c) * HW + px] : 0.f);
+    }
+}
+template <typename T>
+__global__ void nhwc2nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int HW, int ld) {
+    const long total = (long)B * C * HW;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int px = (int)(i % HW);
+        const long p = i / HW;
+        const int c = (int)(p % C);
+        const int b = (int)(p / C);
+        dst[i] = to_f32(src[((long)b * HW + px) * ld + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ loss heads
+__device__ __forceinline__ float ld_any(const void* p, int dtype, long i) {
+    return dtype == PDMK_BF16 ? (float)reinterpret_cast<const bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__global__ void mse_fwd_kernel(const void* __restrict__ a, int adt, const void* __restrict__ b, int bdt,
+                               const float* __restrict__ w, double* __restrict__ out, int slot, long rows_per_b,
+                               int cols, int lda, int ldb, double scale) {
+    const int bi = blockIdx.y;
+    const long total = rows_per_b * cols;
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const long row = (long)bi * rows_per_b + r;
+        const float d = ld_any(a, adt, row * lda + c) - ld_any(b, bdt, row * ldb + c);
+        s += d * d;
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (double)red[0] + red[1] + red[2] + red[3];
+        atomicAdd(&out[slot], tot * scale * (w ? (double)w[bi] : 1.0));
+    }
+}
+__global__ void mse_bwd_kernel(const void* __restrict__ a, int adt, const void* __restrict__ b, int bdt,
+                               const float* __restrict__ w, void* __restrict__ da, long rows_per_b, int cols, int lda,
+                               int ldb, int ldda, float gscale, int acc) {
+    const int bi = blockIdx.y;
+    const long total = rows_per_b * cols;
+    const float gs = gscale * (w ? w[bi] : 1.f);
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        const long row = (long)bi * rows_per_b + r;
+        float g = gs * (ld_any(a, adt, row * lda + c) - ld_any(b, bdt, row * ldb + c));
+        const long o = row * ldda + c;
+        if (adt == PDMK_BF16) {
+            bf16* p = reinterpret_cast<bf16*>(da);
+            p[o] = (bf16)(g + (acc ? (float)p[o] : 0.f));
+        } else {
+            float* p = reinterpret_cast<float*>(da);
+            p[o] = g + (acc ? p[o] : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW / sumsq
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long n, const float* __restrict__ lrp, float b1, float b2, float eps, float wd,
+                             const float* __restrict__ bc, float gscale, int zero_grad) {
+    const float lr = lrp[0], bc1 = bc[0], bc2s = sqrtf(bc[1]);
+    const long nv = n / 4;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < nv; i += (long)gridDim.x * NT) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+        float4 Mv = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &Mv.x; float* vv = &Vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = gg[e] * gscale;
+            pp[e] *= (1.f - lr * wd);
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2s + eps;
+            pp[e] -= (lr / bc1) * (mm[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = Mv;
+        reinterpret_cast<float4*>(v)[i] = Vv;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__global__ void sumsq_kernel(const float* __restrict__ x, long n, double* __restrict__ out, int slot) {
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) s += x[i] * x[i];
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[slot], (double)red[0] + red[1] + red[2] + red[3]);
+}
+
+}  // namespace
+
+extern "C" int pdmk_geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int dtype, pdmk_stream s) {
+    if (!x || !y || M <= 0 || F <= 0) return -1;
+    PDMK_DISPATCH(dtype, geglu_fwd, x, y, M, F, ldx, ldy, (hipStream_t)s);
+}
+extern "C" int pdmk_geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx,
+                              int dtype, pdmk_stream s) {
+    if (!x || !dy || !dx || M <= 0 || F <= 0) return -1;
+    PDMK_DISPATCH(dtype, geglu_bwd, x, dy, dx, M, F, ldx, lddy, lddx, (hipStream_t)s);
+}
+extern "C" int pdmk_silu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream s) {
+    if (!x || !y || n <= 0) return -1;
+    if (dtype == PDMK_BF16) return ew<bf16, 0>(x, x, y, n, 0, 0, (hipStream_t)s);
+    if (dtype == PDMK_F32) return ew<float, 0>(x, x, y, n, 0, 0, (hipStream_t)s);
+    return -2;
+}
+extern "C" int pdmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, pdmk_stream s) {
+    if (!x || !dy || !dx || n <= 0) return -1;
+    if (dtype == PDMK_BF16) return ew<bf16, 1>(x, dy, dx, n, 0, 0, (hipStream_t)s);
+    if (dtype == PDMK_F32) return ew<float, 1>(x, dy, dx, n, 0, 0, (hipStream_t)s);
+    return -2;
+}
+extern "C" int pdmk_axpby(const void* x, void* y, float alpha, float beta, int64_t n, int dtype, pdmk_stream s) {
+    if (!x || !y || n <= 0) return -1;
+    if (dtype == PDMK_BF16) return ew<bf16, 2>(x, x, y, n, alpha, beta, (hipStream_t)s);
+    if (dtype == PDMK_F32) return ew<float, 2>(x, x, y, n, alpha, beta, (hipStream_t)s);
+    return -2;
+}
+extern "C" int pdmk_copy2d(const void* src, void* dst, int64_t rows, int cols, int lds, int ldd, int accumulate,
+                           int dtype, pdmk_stream s) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return -1;
+    PDMK_DISPATCH(dtype, copy2d, src, dst, (long)rows, cols, lds, ldd, accumulate, (hipStream_t)s);
+}
+extern "C" int pdmk_cast_permute(const float* src, void* dst, int n0, int n1, int n2, int mode, int dtype,
+                                 pdmk_stream s) {
+    if (!src || !dst || n0 <= 0 || n1 <= 0 || n2 <= 0 || mode < 0 || mode > 2) return -1;
+    if (mode == 1 && n1 != 1) return -1;
+    PDMK_DISPATCH(dtype, cast_permute, src, dst, n0, n1, n2, mode, (hipStream_t)s);
+}
+extern "C" int pdmk_colsum(const void* x, float* out, int64_t M, int N, int ld, int accumulate, int dtype,
+                           pdmk_stream s) {
+    if (!x || !out || M <= 0 || N <= 0) return -1;
+    PDMK_DISPATCH(dtype, colsum, x, out, (long)M, N, ld, accumulate, (hipStream_t)s);
+}
+extern "C" int pdmk_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, int dtype, pdmk_stream s) {
+    if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
+    PDMK_DISPATCH(dtype, pool, src, dst, B, H, W, C, (hipStream_t)s);
+}
+extern "C" int pdmk_timestep_embed(const int64_t* t, const float* freqs, void* out, int B, int dim, int dtype,
+                                   pdmk_stream s) {
+    if (!t || !freqs || !out || B <= 0 || dim <= 0 || (dim & 1)) return -1;
+    dim3 grid(grid_for((long)B * dim / 2));
+    if (dtype == PDMK_BF16) hipLaunchKernelGGL(temb_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, t, freqs, (bf16*)out, B, dim);
+    else if (dtype == PDMK_F32) hipLaunchKernelGGL(temb_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, t, freqs, (float*)out, B, dim);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_add_noise_velocity(const float* x0, const float* noise, const int64_t* t, const float* sa,
+                                       const float* sb, void* noisy, float* target, int B, int C, int HW, int cpad,
+                                       int dtype, pdmk_stream s) {
+    if (!x0 || !noise || !t || !sa || !sb || !noisy || B <= 0 || C <= 0 || HW <= 0 || cpad < C) return -1;
+    dim3 grid(grid_for((long)B * HW * cpad));
+    if (dtype == PDMK_BF16)
+        hipLaunchKernelGGL(noise_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, x0, noise, t, sa, sb, (bf16*)noisy, target, B, C, HW, cpad);
+    else if (dtype == PDMK_F32)
+        hipLaunchKernelGGL(noise_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, x0, noise, t, sa, sb, (float*)noisy, target, B, C, HW, cpad);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int cpad, int dtype,
+                                 pdmk_stream s) {
+    if (!src || !dst || B <= 0 || C <= 0 || HW <= 0 || cpad < C) return -1;
+    dim3 grid(grid_for((long)B * HW * cpad));
+    if (dtype == PDMK_BF16) hipLaunchKernelGGL(nchw2nhwc_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, src, (bf16*)dst, B, C, HW, cpad);
+    else if (dtype == PDMK_F32) hipLaunchKernelGGL(nchw2nhwc_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, src, (float*)dst, B, C, HW, cpad);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int ld, int dtype, pdmk_stream s) {
+    if (!src || !dst || B <= 0 || C <= 0 || HW <= 0 || ld < C) return -1;
+    dim3 grid(grid_for((long)B * HW * C));
+    if (dtype == PDMK_BF16) hipLaunchKernelGGL(nhwc2nchw_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, (const bf16*)src, dst, B, C, HW, ld);
+    else if (dtype == PDMK_F32) hipLaunchKernelGGL(nhwc2nchw_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, (const float*)src, dst, B, C, HW, ld);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_mse_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, double* out,
+                            int slot, int B, int64_t rows_per_b, int cols, int lda, int ldb, double scale,
+                            pdmk_stream s) {
+    if (!a || !b || !out || B <= 0 || rows_per_b <= 0 || cols <= 0) return -1;
+    if ((a_dtype | b_dtype) & ~1) return -2;
+    dim3 grid(grid_for(rows_per_b * cols, 256), B);
+    hipLaunchKernelGGL(mse_fwd_kernel, grid, dim3(NT), 0, (hipStream_t)s, a, a_dtype, b, b_dtype, w, out, slot,
+                       (long)rows_per_b, cols, lda, ldb, scale);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_mse_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, void* da, int B,
+                            int64_t rows_per_b, int cols, int lda, int ldb, int ldda, float gscale, int accumulate,
+                            pdmk_stream s) {
+    if (!a || !b || !da || B <= 0 || rows_per_b <= 0 || cols <= 0) return -1;
+    if ((a_dtype | b_dtype) & ~1) return -2;
+    dim3 grid(grid_for(rows_per_b * cols, 256), B);
+    hipLaunchKernelGGL(mse_bwd_kernel, grid, dim3(NT), 0, (hipStream_t)s, a, a_dtype, b, b_dtype, w, da,
+                       (long)rows_per_b, cols, lda, ldb, ldda, gscale, accumulate);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
+                          float eps, float weight_decay, const float* bias_corr, float grad_scale, int zero_grad,
+                          pdmk_stream s) {
+    if (!p || !g || !m || !v || !lr || !bias_corr || n <= 0 || (n & 3)) return -1;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
+                       beta1, beta2, eps, weight_decay, bias_corr, grad_scale, zero_grad);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_sumsq(const float* x, int64_t n, double* out, int slot, pdmk_stream s) {
+    if (!x || !out || n <= 0) return -1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048)), dim3(NT), 0, (hipStream_t)s, x, (long)n, out, slot);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,497 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward, NHWC / token-major, HBM-bandwidth kernels.
+// All loads/stores are 16-byte chunks along the channel dim (rows are read fully coalesced); statistics are fp32
+// per thread, fp32 LDS atomics per block, then double atomics across blocks so that E[x^2]-mean^2 is formed in double.
+#include "common.h"
+#include "vec.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAXS = 3;   // chunk slots per thread: C/chunk <= 3*256
+
+struct GnMap {
+    int tpr;   // threads per row (power of two <= 256)
+    int rif;   // rows in flight = 256 / tpr
+};
+__host__ __device__ inline GnMap gn_map(int nchunks) {
+    int tpr = 1;
+    while (tpr < nchunks && tpr < NT) tpr <<= 1;
+    return GnMap{tpr, NT / tpr};
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm fwd
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int HW, int C,
+                                                      int ldx, int G, int gs, int rows_per_blk) {
+    constexpr int V = Vec<T>::N;
+    const int nchunks = C / V;
+    const GnMap mp = gn_map(nchunks);
+    const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    float s[MAXS][V], q[MAXS][V];
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl)
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[sl][e] = q[sl][e] = 0.f;
+    for (int r = r0 + ro; r < r1; r += mp.rif) {
+        const T* row = x + ((long)b * HW + r) * ldx;
+#pragma unroll
+        for (int sl = 0; sl < MAXS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
+                float f[V];
+                Vec<T>::load(row + c * V, f);
+#pragma unroll
+                for (int e = 0; e < V; ++e) { s[sl][e] += f[e]; q[sl][e] += f[e] * f[e]; }
+            }
+        }
+    }
+    __shared__ float ls[2][64];
+    if (tid < 128) ls[tid >> 6][tid & 63] = 0.f;
+    __syncthreads();
+    const int cr = G * gs;
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c * V + e;
+                if (ch < cr) {
+                    const int g = ch / gs;
+                    atomicAdd(&ls[0][g], s[sl][e]);
+                    atomicAdd(&ls[1][g], q[sl][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        atomicAdd(&ws[((long)b * G + tid) * 2 + 0], (double)ls[0][tid]);
+        atomicAdd(&ws[((long)b * G + tid) * 2 + 1], (double)ls[1][tid]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const double* __restrict__ ws, float* __restrict__ stats, int HW,
+                                                      int C, int ldx, int ldy, int G, int gs, float eps, int silu,
+                                                      int rows_per_blk) {
+    constexpr int V = Vec<T>::N;
+    const int nchunks = C / V;
+    const GnMap mp = gn_map(nchunks);
+    const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    __shared__ float lm[64], lr[64];
+    if (tid < G) {
+        const double n = (double)HW * gs;
+        const double mean = ws[((long)b * G + tid) * 2] / n;
+        double var = ws[((long)b * G + tid) * 2 + 1] / n - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        lm[tid] = (float)mean;
+        lr[tid] = rstd;
+        if (blockIdx.x == 0) {
+            stats[((long)b * G + tid) * 2] = (float)mean;
+            stats[((long)b * G + tid) * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    const int cr = G * gs;
+    float sc[MAXS][V], sh[MAXS][V];   // y = x*sc + sh  (pad channels: 0)
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = c * V + e;
+            sc[sl][e] = sh[sl][e] = 0.f;
+            if (c < nchunks && ch < cr) {
+                const int g = ch / gs;
+                const float a = lr[g] * gamma[ch];
+                sc[sl][e] = a;
+                sh[sl][e] = beta[ch] - lm[g] * a;
+            }
+        }
+    }
+    for (int r = r0 + ro; r < r1; r += mp.rif) {
+        const T* row = x + ((long)b * HW + r) * ldx;
+        T* orow = y + ((long)b * HW + r) * ldy;
+#pragma unroll
+        for (int sl = 0; sl < MAXS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
+                float f[V];
+                Vec<T>::load(row + c * V, f);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float z = f[e] * sc[sl][e] + sh[sl][e];
+                    f[e] = silu ? silu_f(z) : z;
+                }
+                Vec<T>::store(orow + c * V, f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm bwd
+// pass 1: per (b,g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat ; per channel dgamma += sum dz*xhat, dbeta += sum dz
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, double* __restrict__ ws, int HW,
+                                                          int C, int ldx, int lddy, int G, int gs, int silu,
+                                                          int rows_per_blk) {
+    constexpr int V = Vec<T>::N;
+    const int nchunks = C / V;
+    const GnMap mp = gn_map(nchunks);
+    const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    const int cr = G * gs;
+    float mean[MAXS][V], rstd[MAXS][V], gm[MAXS][V], bt[MAXS][V];
+    float a1[MAXS][V], a2[MAXS][V];
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = c * V + e;
+            a1[sl][e] = a2[sl][e] = 0.f;
+            mean[sl][e] = rstd[sl][e] = gm[sl][e] = bt[sl][e] = 0.f;
+            if (c < nchunks && ch < cr) {
+                const int g = ch / gs;
+                mean[sl][e] = stats[((long)b * G + g) * 2];
+                rstd[sl][e] = stats[((long)b * G + g) * 2 + 1];
+                gm[sl][e] = gamma[ch];
+                bt[sl][e] = beta[ch];
+            }
+        }
+    }
+    for (int r = r0 + ro; r < r1; r += mp.rif) {
+        const T* row = x + ((long)b * HW + r) * ldx;
+        const T* drow = dy + ((long)b * HW + r) * lddy;
+#pragma unroll
+        for (int sl = 0; sl < MAXS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
+                float f[V], d[V];
+                Vec<T>::load(row + c * V, f);
+                Vec<T>::load(drow + c * V, d);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
+                    float dz = d[e];
+                    if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
+                    a1[sl][e] += dz;
+                    a2[sl][e] += dz * xh;
+                }
+            }
+        }
+    }
+    __shared__ float ls[2][64];
+    if (tid < 128) ls[tid >> 6][tid & 63] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c * V + e;
+                if (ch < cr) {
+                    const int g = ch / gs;
+                    atomicAdd(&ls[0][g], gm[sl][e] * a1[sl][e]);
+                    atomicAdd(&ls[1][g], gm[sl][e] * a2[sl][e]);
+                    unsafeAtomicAdd(&dbeta[ch], a1[sl][e]);
+                    unsafeAtomicAdd(&dgamma[ch], a2[sl][e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < G) {
+        atomicAdd(&ws[((long)b * G + tid) * 2 + 0], (double)ls[0][tid]);
+        atomicAdd(&ws[((long)b * G + tid) * 2 + 1], (double)ls[1][tid]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                          T* __restrict__ dx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats,
+                                                          const double* __restrict__ ws, int HW, int C, int ldx,
+                                                          int lddy, int lddx, int G, int gs, int silu, int accumulate,
+                                                          int rows_per_blk) {
+    constexpr int V = Vec<T>::N;
+    const int nchunks = C / V;
+    const GnMap mp = gn_map(nchunks);
+    const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    const int cr = G * gs;
+    const float invn = 1.0f / ((float)HW * gs);
+    float mean[MAXS][V], rstd[MAXS][V], gm[MAXS][V], bt[MAXS][V], c1[MAXS][V], c2[MAXS][V];
+#pragma unroll
+    for (int sl = 0; sl < MAXS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = c * V + e;
+            mean[sl][e] = rstd[sl][e] = gm[sl][e] = bt[sl][e] = c1[sl][e] = c2[sl][e] = 0.f;
+            if (c < nchunks && ch < cr) {
+                const int g = ch / gs;
+                mean[sl][e] = stats[((long)b * G + g) * 2];
+                rstd[sl][e] = stats[((long)b * G + g) * 2 + 1];
+                gm[sl][e] = gamma[ch];
+                bt[sl][e] = beta[ch];
+                c1[sl][e] = (float)(ws[((long)b * G + g) * 2] * invn);
+                c2[sl][e] = (float)(ws[((long)b * G + g) * 2 + 1] * invn);
+            }
+        }
+    }
+    for (int r = r0 + ro; r < r1; r += mp.rif) {
+        const T* row = x + ((long)b * HW + r) * ldx;
+        const T* drow = dy + ((long)b * HW + r) * lddy;
+        T* orow = dx + ((long)b * HW + r) * lddx;
+#pragma unroll
+        for (int sl = 0; sl < MAXS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
+                float f[V], d[V], o[V];
+                Vec<T>::load(row + c * V, f);
+                Vec<T>::load(drow + c * V, d);
+                if (accumulate) Vec<T>::load(orow + c * V, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
+                    float dz = d[e];
+                    if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
+                    const float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
+                    o[e] = accumulate ? o[e] + v : v;
+                }
+                Vec<T>::store(orow + c * V, o);
+            }
+        }
+    }
+}
+
+inline int gn_rows_per_blk(int B, int HW, int rif) {
+    // aim for ~1024 blocks chip-wide, at least one sweep of rows-in-flight per block
+    int nchunk = max(1, min(HW / max(1, rif), (1024 + B - 1) / B));
+    return (HW + nchunk - 1) / nchunk;
+}
+
+template <typename T>
+int gn_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, double* ws, int B, int HW,
+           int C, int ldx, int ldy, int G, int gs, float eps, int silu, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
+    const GnMap mp = gn_map(C / V);
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif);
+    dim3 grid((HW + rpb - 1) / rpb, B);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) return -1000;
+    hipLaunchKernelGGL(gn_stats_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, ws, HW, C, ldx, G, gs, rpb);
+    hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, ws, stats, HW, C,
+                       ldx, ldy, G, gs, eps, silu, rpb);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta, const float* stats,
+           float* dgamma, float* dbeta, double* ws, int B, int HW, int C, int ldx, int lddy, int lddx, int G, int gs,
+           int silu, int acc, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (C % V || ldx % V || lddy % V || lddx % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
+    const GnMap mp = gn_map(C / V);
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif);
+    dim3 grid((HW + rpb - 1) / rpb, B);
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) return -1000;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
+                       dgamma, dbeta, ws, HW, C, ldx, lddy, G, gs, silu, rpb);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, (T*)dx, gamma, beta,
+                       stats, ws, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+constexpr int LN_MAXS = 5;   // per-lane chunk slots: C <= 5*64*chunk
+constexpr int LN_ROWS_BWD = 8;
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ stats, int M, int C, int ldx, int ldy,
+                                                    float eps) {
+    constexpr int V = Vec<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const int nchunks = C / V;
+    float f[LN_MAXS][V];
+    float sum = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < LN_MAXS; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < nchunks) {
+            Vec<T>::load(x + (long)m * ldx + c * V, f[sl]);
+#pragma unroll
+            for (int e = 0; e < V; ++e) sum += f[sl][e];
+        }
+    }
+    const float mean = wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < LN_MAXS; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) { const float d = f[sl][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
+    if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
+#pragma unroll
+    for (int sl = 0; sl < LN_MAXS; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < nchunks) {
+            float o[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = (f[sl][e] - mean) * rstd * gamma[c * V + e] + beta[c * V + e];
+            Vec<T>::store(y + (long)m * ldy + c * V, o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                    T* __restrict__ dx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ stats, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int M, int C, int ldx, int lddy,
+                                                    int lddx, int accumulate) {
+    constexpr int V = Vec<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = C / V;
+    float gm[LN_MAXS][V], ag[LN_MAXS][V], ab[LN_MAXS][V];
+#pragma unroll
+    for (int sl = 0; sl < LN_MAXS; ++sl) {
+        const int c = lane + 64 * sl;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            ag[sl][e] = ab[sl][e] = 0.f;
+            gm[sl][e] = (c < nchunks) ? gamma[c * V + e] : 0.f;
+        }
+    }
+    const int mbase = (blockIdx.x * 4 + wave) * LN_ROWS_BWD;
+    for (int rr = 0; rr < LN_ROWS_BWD; ++rr) {
+        const int m = mbase + rr;
+        if (m >= M) break;
+        const float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
+        float xh[LN_MAXS][V], d[LN_MAXS][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < LN_MAXS; ++sl) {
+            const int c = lane + 64 * sl;
+            if (c < nchunks) {
+                Vec<T>::load(x + (long)m * ldx + c * V, xh[sl]);
+                Vec<T>::load(dy + (long)m * lddy + c * V, d[sl]);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[sl][e] = (xh[sl][e] - mean) * rstd;
+                    ab[sl][e] += d[sl][e];
+                    ag[sl][e] += d[sl][e] * xh[sl][e];
+                    const float g = d[sl][e] * gm[sl][e];
+                    s1 += g;
+                    s2 += g * xh[sl][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int sl = 0; sl < LN_MAXS; ++sl) {
+            const int c = lane + 64 * sl;
+            if (c < nchunks) {
+                float o[V];
+                if (accumulate) Vec<T>::load(dx + (long)m * lddx + c * V, o);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const float v = rstd * (d[sl][e] * gm[sl][e] - s1 - xh[sl][e] * s2);
+                    o[e] = accumulate ? o[e] + v : v;
+                }
+                Vec<T>::store(dx + (long)m * lddx + c * V, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < LN_MAXS; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < nchunks) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                unsafeAtomicAdd(&dgamma[c * V + e], ag[sl][e]);
+                unsafeAtomicAdd(&dbeta[c * V + e], ab[sl][e]);
+            }
+        }
+    }
+}
+
+template <typename T>
+int ln_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M, int C, int ldx, int ldy,
+           float eps, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (C % V || ldx % V || ldy % V || C / V > LN_MAXS * 64) return -1;
+    hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3((M + 3) / 4), dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, stats, M,
+                       C, ldx, ldy, eps);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T>
+int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats, float* dgamma,
+           float* dbeta, int M, int C, int ldx, int lddy, int lddx, int acc, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64) return -1;
+    const int rows_per_blk = 4 * LN_ROWS_BWD;
+    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((M + rows_per_blk - 1) / rows_per_blk), dim3(NT), 0, st, (const T*)x,
+                       (const T*)dy, (T*)dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, acc);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                  double* ws, int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps,
+                                  int silu, int dtype, pdmk_stream stream) {
+    if (!x || !y || !gamma || !beta || !stats || !ws || B <= 0 || HW <= 0 || G <= 0 || gs <= 0) return -1;
+    PDMK_DISPATCH(dtype, gn_fwd, x, y, gamma, beta, stats, ws, B, HW, C, ldx, ldy, G, gs, eps, silu,
+                  (hipStream_t)stream);
+}
+extern "C" int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
+                                  const float* stats, float* dgamma, float* dbeta, double* ws, int B, int HW, int C,
+                                  int ldx, int lddy, int lddx, int G, int gs, int silu, int accumulate_dx, int dtype,
+                                  pdmk_stream stream) {
+    if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !ws || B <= 0 || HW <= 0) return -1;
+    PDMK_DISPATCH(dtype, gn_bwd, x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, C, ldx, lddy, lddx, G, gs,
+                  silu, accumulate_dx, (hipStream_t)stream);
+}
+extern "C" int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M,
+                                  int C, int ldx, int ldy, float eps, int dtype, pdmk_stream stream) {
+    if (!x || !y || !gamma || !beta || !stats || M <= 0) return -1;
+    PDMK_DISPATCH(dtype, ln_fwd, x, y, gamma, beta, stats, M, C, ldx, ldy, eps, (hipStream_t)stream);
+}
+extern "C" int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
+                                  float* dgamma, float* dbeta, int M, int C, int ldx, int lddy, int lddx,
+                                  int accumulate_dx, int dtype, pdmk_stream stream) {
+    if (!x || !dy || !dx || !gamma || !stats || !dgamma || !dbeta || M <= 0) return -1;
+    PDMK_DISPATCH(dtype, ln_bwd, x, dy, dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, accumulate_dx,
+                  (hipStream_t)stream);
+}

@@ -1,0 +1,224 @@
+"""ctypes binding of libpdmk.so (include/pdmk.h) — the only route from the Python host side to the HIP kernels.
+
+There is NO fallback: if the shared library is missing or a call returns a non-zero status this module raises.
+torch is used for device memory and streams only (tensors are passed as raw device pointers).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpdmk.so")
+
+F32, BF16 = 0, 1
+A_ROWK, A_CONV, A_COLK = 0, 1, 2
+B_ROWK, B_COLK, B_COLK_CONV = 0, 1, 2
+
+
+class PdmkError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise PdmkError(f"libpdmk.so not found at {LIB_PATH}: build it with `python __graft_entry__.py` "
+                        f"(or `make -C unlearn-ft_amd/csrc`); there is no CPU/PyTorch fallback for the hot path")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+
+vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("rowvec", vp), ("R", vp),
+                ("M", i32), ("N", i32), ("K", i32),
+                ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
+                ("rows_per_b", i32), ("a_mode", i32), ("b_mode", i32),
+                ("conv_b", i32), ("conv_hi", i32), ("conv_wi", i32), ("conv_ci", i32), ("conv_ho", i32),
+                ("conv_wo", i32), ("conv_mode", i32), ("conv_ld", i32),
+                ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32)]
+
+
+_SIGS = {
+    "pdmk_version": ([], i32),
+    "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
+    "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
+    "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
+    "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
+    "pdmk_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
+                       i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
+    "pdmk_geglu_fwd": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_geglu_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_silu_fwd": ([vp, vp, i64, i32, vp], i32),
+    "pdmk_silu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
+    "pdmk_copy2d": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_cast_permute": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_colsum": ([vp, vp, i64, i32, i32, i32, i32, vp], i32),
+    "pdmk_pool2x2_sum": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_timestep_embed": ([vp, vp, vp, i32, i32, i32, vp], i32),
+    "pdmk_add_noise_velocity": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_nchw_to_nhwc": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_mse_fwd": ([vp, i32, vp, i32, vp, vp, i32, i32, i64, i32, i32, i32, f64, vp], i32),
+    "pdmk_mse_bwd": ([vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, i32, i32, f32, i32, vp], i32),
+    "pdmk_axpby": ([vp, vp, f32, f32, i64, i32, vp], i32),
+    "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp], i32),
+    "pdmk_sumsq": ([vp, i64, vp, i32, vp], i32),
+}
+for _n, (_a, _r) in _SIGS.items():
+    _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
+    _f.argtypes, _f.restype = _a, _r
+
+EXPORTS = tuple(_SIGS)
+
+
+def version():
+    return _lib.pdmk_version()
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise PdmkError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise PdmkError(f"{name} failed with status {rc}")
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
+         a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0):
+    """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None."""
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(A), _p(B), _p(Cout)
+    g.bias, g.rowvec, g.R = _p(bias), _p(rowvec), _p(R)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc, g.ldr = lda, ldb, ldc, ldr
+    g.rows_per_b = rows_per_b
+    g.a_mode, g.b_mode = a_mode, b_mode
+    if conv is not None:
+        (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
+    g.dtype = dt(A) if dtype is None else dtype
+    g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
+    _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+
+
+def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps, silu):
+    _chk(_lib.pdmk_groupnorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), _p(ws), B, HW, Cc, ldx, ldy, G, gs,
+                                 eps, int(silu), dt(x), _st()), "pdmk_groupnorm_fwd")
+
+
+def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc):
+    _chk(_lib.pdmk_groupnorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), _p(ws),
+                                 B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), dt(x), _st()),
+         "pdmk_groupnorm_bwd")
+
+
+def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
+    _chk(_lib.pdmk_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), M, Cc, ldx, ldy, eps, dt(x), _st()),
+         "pdmk_layernorm_fwd")
+
+
+def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc):
+    _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), M, Cc, ldx, lddy,
+                                 lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
+
+
+def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale):
+    """qs/ks/vs/os_ = (batch_stride, row_stride) in elements."""
+    _chk(_lib.pdmk_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, qs[0], qs[1], ks[0], ks[1], vs[0],
+                            vs[1], os_[0], os_[1], scale, dt(q), _st()), "pdmk_attn_fwd")
+
+
+def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_, dqs, dks, dvs, scale):
+    _chk(_lib.pdmk_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Nq,
+                            Nk, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], dqs[0], dqs[1], dks[0],
+                            dks[1], dvs[0], dvs[1], scale, dt(q), _st()), "pdmk_attn_bwd")
+
+
+def geglu_fwd(x, y, M, Fd, ldx, ldy):
+    _chk(_lib.pdmk_geglu_fwd(_p(x), _p(y), M, Fd, ldx, ldy, dt(x), _st()), "pdmk_geglu_fwd")
+
+
+def geglu_bwd(x, dy, dx, M, Fd, ldx, lddy, lddx):
+    _chk(_lib.pdmk_geglu_bwd(_p(x), _p(dy), _p(dx), M, Fd, ldx, lddy, lddx, dt(x), _st()), "pdmk_geglu_bwd")
+
+
+def silu_fwd(x, y):
+    _chk(_lib.pdmk_silu_fwd(_p(x), _p(y), x.numel(), dt(x), _st()), "pdmk_silu_fwd")
+
+
+def silu_bwd(x, dy, dx):
+    _chk(_lib.pdmk_silu_bwd(_p(x), _p(dy), _p(dx), x.numel(), dt(x), _st()), "pdmk_silu_bwd")
+
+
+def copy2d(src, dst, rows, cols, lds, ldd, accumulate=False):
+    _chk(_lib.pdmk_copy2d(_p(src), _p(dst), rows, cols, lds, ldd, int(accumulate), dt(src), _st()), "pdmk_copy2d")
+
+
+def cast_permute(src, dst, n0, n1, n2, mode):
+    _chk(_lib.pdmk_cast_permute(_p(src), _p(dst), n0, n1, n2, mode, dt(dst), _st()), "pdmk_cast_permute")
+
+
+def colsum(x, out, M, N, ld, accumulate=False):
+    _chk(_lib.pdmk_colsum(_p(x), _p(out), M, N, ld, int(accumulate), dt(x), _st()), "pdmk_colsum")
+
+
+def pool2x2_sum(src, dst, B, H, W, Cc):
+    _chk(_lib.pdmk_pool2x2_sum(_p(src), _p(dst), B, H, W, Cc, dt(src), _st()), "pdmk_pool2x2_sum")
+
+
+def timestep_embed(t, freqs, out, B, dim):
+    _chk(_lib.pdmk_timestep_embed(_p(t), _p(freqs), _p(out), B, dim, dt(out), _st()), "pdmk_timestep_embed")
+
+
+def add_noise_velocity(x0, noise, t, sa, sb, noisy, target, B, Cc, HW, cpad):
+    _chk(_lib.pdmk_add_noise_velocity(_p(x0), _p(noise), _p(t), _p(sa), _p(sb), _p(noisy), _p(target), B, Cc, HW, cpad,
+                                      dt(noisy), _st()), "pdmk_add_noise_velocity")
+
+
+def nchw_to_nhwc(src, dst, B, Cc, HW, cpad):
+    _chk(_lib.pdmk_nchw_to_nhwc(_p(src), _p(dst), B, Cc, HW, cpad, dt(dst), _st()), "pdmk_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src, dst, B, Cc, HW, ld):
+    _chk(_lib.pdmk_nhwc_to_nchw(_p(src), _p(dst), B, Cc, HW, ld, dt(src), _st()), "pdmk_nhwc_to_nchw")
+
+
+def mse_fwd(a, b, w, out, slot, B, rows_per_b, cols, lda, ldb, scale):
+    _chk(_lib.pdmk_mse_fwd(_p(a), dt(a), _p(b), dt(b), _p(w), _p(out), slot, B, rows_per_b, cols, lda, ldb,
+                           float(scale), _st()), "pdmk_mse_fwd")
+
+
+def mse_bwd(a, b, w, da, B, rows_per_b, cols, lda, ldb, ldda, gscale, accumulate):
+    _chk(_lib.pdmk_mse_bwd(_p(a), dt(a), _p(b), dt(b), _p(w), _p(da), B, rows_per_b, cols, lda, ldb, ldda,
+                           float(gscale), int(accumulate), _st()), "pdmk_mse_bwd")
+
+
+def axpby(x, y, alpha, beta):
+    _chk(_lib.pdmk_axpby(_p(x), _p(y), float(alpha), float(beta), x.numel(), dt(x), _st()), "pdmk_axpby")
+
+
+def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bias_corr, grad_scale, zero_grad):
+    _chk(_lib.pdmk_adamw(_p(p), _p(g), _p(m), _p(v), n, _p(lr), b1, b2, eps, wd, _p(bias_corr), grad_scale,
+                         int(zero_grad), _st()), "pdmk_adamw")
+
+
+def sumsq(x, n, out, slot):
+    _chk(_lib.pdmk_sumsq(_p(x), n, _p(out), slot, _st()), "pdmk_sumsq")
