@@ -1,0 +1,1 @@
+__version__ = "2.2.0+mi355x.r1"

@@ -1,0 +1,362 @@
+"""Executor of the pruned / dense SD-2.1 U-Net on libpdmk: explicit forward + hand-written backward (no autograd).
+
+Dataflow = UNet2DConditionModelGated.forward (pdm/models/unet/unet_2d_conditional.py:1417-1728) with the leaves of
+SURVEY Appendix B; activations are token-major / NHWC 2-D matrices [B*H*W, C] so conv outputs feed the transformer
+GEMMs (and back) without any layout change.  Every op appends its backward closure to a tape; `backward()` replays the
+tape in reverse.  Gradients w.r.t. parameters are ACCUMULATED into the fp32 grad arena (zeroed by the fused AdamW).
+Gradient fan-in (residuals, skip connections, the shared time embedding) is done in GEMM / norm epilogues
+(accumulate flags) or by aliasing a finished gradient buffer - there are no standalone "add" passes on the hot path.
+"""
+import math
+
+import torch
+
+from ... import _pdmk as k
+from .params import ParamStore
+from .spec import UNetConfig, pad8
+
+
+class Act:
+    """A 2-D activation [rows, cols] (row stride = t.stride(0)) and its gradient (same logical shape)."""
+    __slots__ = ("t", "g", "rg")
+
+    def __init__(self, t, rg=True):
+        self.t, self.g, self.rg = t, None, rg
+
+
+def _ld(t):
+    return t.stride(0)
+
+
+class UNetEngine:
+    def __init__(self, cfg: UNetConfig, blocks, store: ParamStore, dtype):
+        self.cfg, self.blocks, self.P, self.dtype = cfg, blocks, store, dtype
+        self.dev = store.master.device
+        half = cfg.block_out_channels[0] // 2
+        # frequency table of Timesteps(dim, flip_sin_to_cos=True, shift=0): built exactly like the reference (fp32 exp)
+        self.freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(self.dev)
+        self.ws = torch.zeros(64 * 64 * 2, device=self.dev, dtype=torch.float64)   # GN scratch: B*G*2 doubles
+        self.tape = []
+        self.train = False
+        self.macs = 0
+        self.count_macs = False
+        self.grad_ready_cb = None      # called with an arena offset: every gradient at or beyond it is final
+
+    # ------------------------------------------------------------------ helpers
+    def _empty(self, rows, cols, dtype=None):
+        return torch.empty((rows, cols), device=self.dev, dtype=dtype or self.dtype)
+
+    def _grad_into(self, act, rows, cols):
+        """Returns (tensor, accumulate) for writing d(act)."""
+        if act.g is None:
+            act.g = self._empty(rows, cols, act.t.dtype)
+            return act.g, False
+        return act.g, True
+
+    def _give(self, act, dy):
+        """act.g += dy where dy is a finished gradient buffer (aliased when act has no gradient yet)."""
+        if not act.rg:
+            return
+        if act.g is None:
+            act.g = dy
+        else:
+            k.copy2d(dy, act.g, dy.shape[0], dy.shape[1], _ld(dy), _ld(act.g), accumulate=True)
+
+    @staticmethod
+    def _splitk(m_out, n_out, red, step):
+        tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
+        nk = max(1, red // step)
+        return max(1, min(512 // max(tiles, 1), nk // 8, 64))
+
+    # ------------------------------------------------------------------ ops
+    def linear(self, x, key, bias=None, residual=None, out_f32=False):
+        P = self.P
+        e = P.by_key[key + ".weight"]
+        Np, Kp = e.shape
+        M = x.t.shape[0]
+        assert x.t.shape[1] == Kp, f"{key}: input has {x.t.shape[1]} cols, weight expects {Kp}"
+        y = self._empty(M, Np, torch.float32 if out_f32 else None)
+        k.gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np,
+               bias=P.p(bias) if bias else None, R=residual.t if residual else None,
+               ldr=_ld(residual.t) if residual else 0, out_f32=out_f32)
+        if self.count_macs:
+            self.macs += M * e.logical[0] * e.logical[1]
+        out = Act(y)
+        if self.train:
+            def bwd():
+                dy = out.g
+                if dy.dtype != self.dtype:        # fp32 output (time-embedding projections): tiny cast for the GEMMs
+                    dyc = self._empty(M, Np)
+                    k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
+                    dy = dyc
+                if x.rg:
+                    dx, acc = self._grad_into(x, M, Kp)
+                    k.gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc)
+                sk = self._splitk(Np, Kp, M, 32)
+                k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
+                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t))
+                if bias:
+                    k.colsum(dy, P.g(bias), M, Np, _ld(dy), accumulate=True)
+                if residual is not None:
+                    self._give(residual, out.g)
+            self.tape.append(bwd)
+        return out
+
+    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None):
+        """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather."""
+        P = self.P
+        e = P.by_key[key + ".weight"]
+        Cop, _, Cip = e.shape
+        assert x.t.shape[1] == Cip, f"{key}: input has {x.t.shape[1]} channels, weight expects {Cip}"
+        Ho, Wo = ((Hi + 1) // 2, (Wi + 1) // 2) if mode == 1 else ((2 * Hi, 2 * Wi) if mode == 2 else (Hi, Wi))
+        M = B * Ho * Wo
+        y = self._empty(M, Cop)
+        k.gemm(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
+               conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
+               rowvec=rowvec.t if rowvec is not None else None, rows_per_b=Ho * Wo,
+               R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0)
+        if self.count_macs:
+            self.macs += M * e.logical[0] * e.logical[1] * 9
+        out = Act(y)
+        if self.train:
+            def bwd():
+                dy = out.g
+                ldy = _ld(dy)
+                if x.rg:
+                    if mode == 2:
+                        tmp = self._empty(M, Cip)
+                        k.gemm(dy, P.wtv(key + ".weight"), tmp, M, Cip, 9 * Cop, 0, 9 * Cop, Cip, a_mode=k.A_CONV,
+                               conv=(B, Ho, Wo, Cop, Ho, Wo, 0, ldy))
+                        pooled = self._empty(B * Hi * Wi, Cip)
+                        k.pool2x2_sum(tmp, pooled, B, Hi, Wi, Cip)
+                        self._give(x, pooled)
+                    else:
+                        dx, acc = self._grad_into(x, B * Hi * Wi, Cip)
+                        k.gemm(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
+                               a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
+                               accumulate=acc)
+                sk = self._splitk(Cop, 9 * Cip, M, 32)
+                k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
+                       b_mode=k.B_COLK_CONV, conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), out_f32=True, splitk=sk,
+                       accumulate=(sk == 1), dtype=k.dt(x.t))
+                if rowvec is not None:
+                    # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
+                    dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
+                    hw = Ho * Wo
+                    for b in range(B):
+                        k.colsum(dy[b * hw:(b + 1) * hw], dtp[b], hw, Cop, ldy)
+                    k.colsum(dtp, P.g(bias), B, Cop, Cop, accumulate=True)
+                    rowvec.g = dtp
+                else:
+                    k.colsum(dy, P.g(bias), M, Cop, ldy, accumulate=True)
+                if residual is not None:
+                    self._give(residual, dy)
+            self.tape.append(bwd)
+        return out, Ho, Wo
+
+    def groupnorm(self, x, key, B, HW, G, gs, eps, silu):
+        P = self.P
+        C = x.t.shape[1]
+        y = self._empty(B * HW, C)
+        stats = torch.empty((B, G, 2), device=self.dev, dtype=torch.float32)
+        gw, gb = P.p(key + ".weight"), P.p(key + ".bias")
+        k.groupnorm_fwd(x.t, y, gw, gb, stats, self.ws, B, HW, C, _ld(x.t), C, G, gs, eps, silu)
+        out = Act(y)
+        if self.train:
+            def bwd():
+                dx, acc = self._grad_into(x, B * HW, C)
+                k.groupnorm_bwd(x.t, out.g, dx, gw, gb, stats, P.g(key + ".weight"), P.g(key + ".bias"), self.ws, B,
+                                HW, C, _ld(x.t), _ld(out.g), _ld(dx), G, gs, silu, acc)
+            self.tape.append(bwd)
+        return out
+
+    def layernorm(self, x, key):
+        P = self.P
+        M, C = x.t.shape
+        y = self._empty(M, C)
+        stats = torch.empty((M, 2), device=self.dev, dtype=torch.float32)
+        gw = P.p(key + ".weight")
+        k.layernorm_fwd(x.t, y, gw, P.p(key + ".bias"), stats, M, C, _ld(x.t), C, 1e-5)
+        out = Act(y)
+        if self.train:
+            def bwd():
+                dx, acc = self._grad_into(x, M, C)
+                k.layernorm_bwd(x.t, out.g, dx, gw, stats, P.g(key + ".weight"), P.g(key + ".bias"), M, C, _ld(x.t),
+                                _ld(out.g), _ld(dx), acc)
+            self.tape.append(bwd)
+        return out
+
+    def attention(self, q, kk, v, B, H, Nq, Nk, q_act, kv_act, q_cols, kv_cols):
+        """q/kk/v: 2-D views [B*N, H*64] (column slices of the projection outputs); *_act own the gradients;
+        q_cols / kv_cols = (lo, hi) column ranges of q in q_act and of (k, v) in kv_act."""
+        d = H * 64
+        o = self._empty(B * Nq, d)
+        lse = torch.empty((B, H, Nq), device=self.dev, dtype=torch.float32)
+        qs, ks, vs = (Nq * _ld(q), _ld(q)), (Nk * _ld(kk), _ld(kk)), (Nk * _ld(v), _ld(v))
+        os_ = (Nq * d, d)
+        scale = 64 ** -0.5
+        k.attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale)
+        if self.count_macs:
+            self.macs += 2 * B * H * Nq * Nk * 64
+        out = Act(o)
+        if self.train:
+            def bwd():
+                delta = torch.empty((B, H, Nq), device=self.dev, dtype=torch.float32)
+                if q_act.g is None:
+                    q_act.g = self._empty(*q_act.t.shape)
+                if kv_act.rg and kv_act.g is None:
+                    kv_act.g = self._empty(*kv_act.t.shape)
+                dq = q_act.g[:, q_cols[0]:q_cols[1]]
+                if kv_act.rg:
+                    dk = kv_act.g[:, kv_cols[0][0]:kv_cols[0][1]]
+                    dv = kv_act.g[:, kv_cols[1][0]:kv_cols[1][1]]
+                else:      # text conditioning does not need gradients, but the kernel writes dK/dV: scratch
+                    scratch = self._empty(B * Nk, 2 * d)
+                    dk, dv = scratch[:, :d], scratch[:, d:]
+                k.attn_bwd(q, kk, v, o, out.g, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_,
+                           (Nq * _ld(dq), _ld(dq)), (Nk * _ld(dk), _ld(dk)), (Nk * _ld(dv), _ld(dv)), scale)
+            self.tape.append(bwd)
+        return out
+
+    def geglu(self, x):
+        M, F2 = x.t.shape
+        Fd = F2 // 2
+        y = self._empty(M, Fd)
+        k.geglu_fwd(x.t, y, M, Fd, _ld(x.t), Fd)
+        out = Act(y)
+        if self.train:
+            def bwd():
+                assert x.g is None
+                x.g = self._empty(M, F2)
+                k.geglu_bwd(x.t, out.g, x.g, M, Fd, _ld(x.t), _ld(out.g), F2)
+            self.tape.append(bwd)
+        return out
+
+    def silu(self, x):
+        y = torch.empty_like(x.t)
+        k.silu_fwd(x.t, y)
+        out = Act(y)
+        if self.train:
+            def bwd():
+                assert x.g is None and out.g.is_contiguous()
+                x.g = torch.empty_like(x.t)
+                k.silu_bwd(x.t, out.g, x.g)
+            self.tape.append(bwd)
+        return out
+
+    def concat(self, a, b):
+        M, Ca, Cb = a.t.shape[0], a.t.shape[1], b.t.shape[1]
+        cat = self._empty(M, Ca + Cb)
+        k.copy2d(a.t, cat, M, Ca, _ld(a.t), Ca + Cb)
+        k.copy2d(b.t, cat[:, Ca:], M, Cb, _ld(b.t), Ca + Cb)
+        out = Act(cat)
+        if self.train:
+            def bwd():
+                self._give(a, out.g[:, :Ca])
+                self._give(b, out.g[:, Ca:])
+            self.tape.append(bwd)
+        return out
+
+    # ------------------------------------------------------------------ blocks
+    def _mark(self, first_key):
+        """Tape marker placed at the START of a block: it runs after the whole block's backward, i.e. when every
+        gradient from this block's first arena entry to the end of the arena is final (bucketed all-reduce trigger)."""
+        if self.train:
+            off = self.P.by_key[first_key].off
+            self.tape.append(lambda: self.grad_ready_cb(off) if self.grad_ready_cb else None)
+
+    def resblock(self, x, r, st, B, H, W):
+        G = self.cfg.norm_num_groups
+        p = r.name
+        self._mark(p + ".norm1.weight")
+        n1 = self.groupnorm(x, p + ".norm1", B, H * W, G, r.cin // G, 1e-5, True)
+        tp = self.linear(st, p + ".time_emb_proj", bias=p + ".time_emb_proj.bias", out_f32=True)
+        h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=tp)
+        n2 = self.groupnorm(h1, p + ".norm2", B, H * W, r.groups2(G), r.cout // G, 1e-5, True)
+        res = x if r.cin == r.cout else self.linear(x, p + ".conv_shortcut", bias=p + ".conv_shortcut.bias")
+        out, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res)
+        return out
+
+    def transformer(self, x, a, ehs, B, H, W, T):
+        G = self.cfg.norm_num_groups
+        p, c, N = a.name, a.c, H * W
+        t = p + ".transformer_blocks.0"
+        d1, d2 = a.h1() * 64, a.h2() * 64
+        self._mark(p + ".norm.weight")
+        n = self.groupnorm(x, p + ".norm", B, N, G, c // G, 1e-6, False)
+        h = self.linear(n, p + ".proj_in", bias=p + ".proj_in.bias")
+        l1 = self.layernorm(h, t + ".norm1")
+        qkv = self.linear(l1, t + ".attn1.to_qkv")
+        o = self.attention(qkv.t[:, :d1], qkv.t[:, d1:2 * d1], qkv.t[:, 2 * d1:3 * d1], B, a.h1(), N, N, qkv, qkv,
+                           (0, d1), ((d1, 2 * d1), (2 * d1, 3 * d1)))
+        h = self.linear(o, t + ".attn1.to_out.0", bias=t + ".attn1.to_out.0.bias", residual=h)
+        l2 = self.layernorm(h, t + ".norm2")
+        q = self.linear(l2, t + ".attn2.to_q")
+        kv = self.linear(ehs, t + ".attn2.to_kv")
+        kv.rg = self.train
+        o = self.attention(q.t[:, :d2], kv.t[:, :d2], kv.t[:, d2:2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
+                           ((0, d2), (d2, 2 * d2)))
+        h = self.linear(o, t + ".attn2.to_out.0", bias=t + ".attn2.to_out.0.bias", residual=h)
+        l3 = self.layernorm(h, t + ".norm3")
+        f = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias")
+        gl = self.geglu(f)
+        h = self.linear(gl, t + ".ff.net.2", bias=t + ".ff.net.2.bias", residual=h)
+        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x)
+
+    # ------------------------------------------------------------------ whole model
+    def forward(self, x, timesteps, ehs, B, H, W, train):
+        """x: [B*H*W, pad8(in_channels)] NHWC rows in self.dtype; timesteps int64 [B]; ehs: [B*T, ctx] in self.dtype.
+        Returns (pred Act [B*H*W, pad8(out_channels)], acts {d0..,m,u0..: Act})."""
+        cfg = self.cfg
+        self.train = train
+        self.tape = []
+        T = ehs.shape[0] // B
+        c0 = cfg.block_out_channels[0]
+        te = self._empty(B, c0)
+        k.timestep_embed(timesteps, self.freqs, te, B, c0)
+        e1 = self.linear(Act(te, rg=False), "time_embedding.linear_1", bias="time_embedding.linear_1.bias")
+        temb = self.linear(self.silu(e1), "time_embedding.linear_2", bias="time_embedding.linear_2.bias")
+        st = self.silu(temb)                      # shared by every ResBlock (blocks.py:336)
+        ehs_act = Act(ehs, rg=False)
+        h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias")
+        skips = [h]
+        acts = {}
+        for b in self.blocks:
+            if b.kind == "down":
+                for j, r in enumerate(b.resnets):
+                    if not r.dropped:
+                        h = self.resblock(h, r, st, B, H, W)
+                    if b.attns and not b.attns[j].dropped:
+                        h = self.transformer(h, b.attns[j], ehs_act, B, H, W, T)
+                    skips.append(h)
+                if b.sampler:
+                    h, H, W = self.conv3(h, f"{b.name}.downsamplers.0.conv", B, H, W, 1,
+                                         f"{b.name}.downsamplers.0.conv.bias")
+                    skips.append(h)
+                acts[f"d{b.idx}"] = h
+            elif b.kind == "mid":
+                h = self.resblock(h, b.resnets[0], st, B, H, W)
+                h = self.transformer(h, b.attns[0], ehs_act, B, H, W, T)
+                h = self.resblock(h, b.resnets[1], st, B, H, W)
+                acts["m"] = h
+            else:
+                for j, r in enumerate(b.resnets):
+                    s = skips.pop()
+                    if not r.dropped:      # dropped: keep the non-skip channels == h itself (blocks.py:502-515)
+                        h = self.resblock(self.concat(h, s), r, st, B, H, W)
+                    if b.attns and not b.attns[j].dropped:
+                        h = self.transformer(h, b.attns[j], ehs_act, B, H, W, T)
+                if b.sampler:
+                    h, H, W = self.conv3(h, f"{b.name}.upsamplers.0.conv", B, H, W, 2,
+                                         f"{b.name}.upsamplers.0.conv.bias")
+                acts[f"u{b.idx}"] = h
+        assert not skips
+        n = self.groupnorm(h, "conv_norm_out", B, H * W, cfg.norm_num_groups, c0 // cfg.norm_num_groups, 1e-5, True)
+        pred, _, _ = self.conv3(n, "conv_out", B, H, W, 0, "conv_out.bias")
+        return pred, acts
+
+    def backward(self):
+        """Replays the tape; the caller has seeded .g of the loss inputs (pred and, optionally, block activations)."""
+        tape, self.tape = self.tape, []
+        for fn in reversed(tape):
+            fn()

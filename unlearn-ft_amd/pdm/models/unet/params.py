@@ -1,0 +1,271 @@
+"""Flat parameter arenas for the MI355X engine.
+
+One fp32 master arena (+ grad arena, + AdamW moments owned by the optimiser) holds every parameter in its *packed*
+kernel layout, in forward order:
+  conv3x3   [Co_p][9 taps][Ci_p]            (diffusers OIHW -> O,ky,kx,I; channel dims zero-padded to multiples of 8)
+  linear    [N_p][K_p]                      (q|k|v of self-attention and k|v of cross-attention fused row-wise)
+  vectors   biases / norm affine, fp32 only
+and two compute-dtype arenas with the same offsets: `w` (forward layout) and `wt` (dgrad layout: Linear W^T, conv
+[Ci_p][9 flipped][Co_p]) refreshed from the master after every optimiser step.  Zero padding is a fixed point of the
+training step (padded rows/cols receive zero gradients), so the packed model is exactly the pruned model.
+State-dict import/export uses the diffusers SD U-Net key names with the *pruned* shapes, i.e. the checkpoint format of
+trainer.py:314-346 (safetensors written by save_pretrained / read by load_state_dict).
+"""
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import torch
+
+from ... import _pdmk as k
+from .spec import UNetConfig, pad8
+
+
+@dataclass
+class Entry:
+    key: str                              # arena key, e.g. "mid_block.resnets.0.conv1.weight"
+    kind: str                             # conv3 | lin | vec
+    shape: Tuple[int, ...]                # packed shape
+    srcs: List[Tuple[str, int]]           # [(state-dict name, rows)] concatenated along dim 0
+    logical: Tuple[int, ...]              # logical (unpadded) shape of the concatenation: (n, k) | (co, ci) | (n,)
+    off: int = 0
+
+    @property
+    def numel(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+
+def _conv(key, co, ci):
+    return Entry(key + ".weight", "conv3", (pad8(co), 9, pad8(ci)), [(key + ".weight", co)], (co, ci))
+
+
+def _lin(key, srcs, k_in, suffix=".weight"):
+    n = sum(r for _, r in srcs)
+    return Entry(key + suffix, "lin", (pad8(n), pad8(k_in)), srcs, (n, k_in))
+
+
+def _vec(key, srcs):
+    n = sum(r for _, r in srcs)
+    return Entry(key, "vec", (pad8(n),), srcs, (n,))
+
+
+def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
+    G = cfg.norm_num_groups
+    E: List[Entry] = []
+    c0 = cfg.block_out_channels[0]
+    E += [_conv("conv_in", c0, cfg.in_channels), _vec("conv_in.bias", [("conv_in.bias", c0)])]
+    for nm, (ki, no) in (("time_embedding.linear_1", (c0, cfg.temb_dim)),
+                         ("time_embedding.linear_2", (cfg.temb_dim, cfg.temb_dim))):
+        E += [_lin(nm, [(nm + ".weight", no)], ki), _vec(nm + ".bias", [(nm + ".bias", no)])]
+
+    def res_entries(r):
+        if r.dropped:
+            return []
+        p, ci = r.name, r.inner(G)
+        out = [_vec(f"{p}.norm1.weight", [(f"{p}.norm1.weight", r.cin)]),
+               _vec(f"{p}.norm1.bias", [(f"{p}.norm1.bias", r.cin)]),
+               _conv(f"{p}.conv1", ci, r.cin), _vec(f"{p}.conv1.bias", [(f"{p}.conv1.bias", ci)]),
+               _lin(f"{p}.time_emb_proj", [(f"{p}.time_emb_proj.weight", ci)], cfg.temb_dim),
+               _vec(f"{p}.time_emb_proj.bias", [(f"{p}.time_emb_proj.bias", ci)]),
+               _vec(f"{p}.norm2.weight", [(f"{p}.norm2.weight", ci)]),
+               _vec(f"{p}.norm2.bias", [(f"{p}.norm2.bias", ci)]),
+               _conv(f"{p}.conv2", r.cout, ci), _vec(f"{p}.conv2.bias", [(f"{p}.conv2.bias", r.cout)])]
+        if r.cin != r.cout:
+            out += [_lin(f"{p}.conv_shortcut", [(f"{p}.conv_shortcut.weight", r.cout)], r.cin),
+                    _vec(f"{p}.conv_shortcut.bias", [(f"{p}.conv_shortcut.bias", r.cout)])]
+        return out
+
+    def attn_entries(a):
+        if a.dropped:
+            return []
+        p, c = a.name, a.c
+        t = p + ".transformer_blocks.0"
+        d1, d2, ff = a.h1() * 64, a.h2() * 64, a.ff(cfg.ff_gate_width)
+        out = [_vec(f"{p}.norm.weight", [(f"{p}.norm.weight", c)]), _vec(f"{p}.norm.bias", [(f"{p}.norm.bias", c)]),
+               _lin(f"{p}.proj_in", [(f"{p}.proj_in.weight", c)], c), _vec(f"{p}.proj_in.bias", [(f"{p}.proj_in.bias", c)])]
+        for i in (1, 2, 3):
+            out += [_vec(f"{t}.norm{i}.weight", [(f"{t}.norm{i}.weight", c)]),
+                    _vec(f"{t}.norm{i}.bias", [(f"{t}.norm{i}.bias", c)])]
+        out += [_lin(f"{t}.attn1.to_qkv", [(f"{t}.attn1.to_q.weight", d1), (f"{t}.attn1.to_k.weight", d1),
+                                            (f"{t}.attn1.to_v.weight", d1)], c),
+                _lin(f"{t}.attn1.to_out.0", [(f"{t}.attn1.to_out.0.weight", c)], d1),
+                _vec(f"{t}.attn1.to_out.0.bias", [(f"{t}.attn1.to_out.0.bias", c)]),
+                _lin(f"{t}.attn2.to_q", [(f"{t}.attn2.to_q.weight", d2)], c),
+                _lin(f"{t}.attn2.to_kv", [(f"{t}.attn2.to_k.weight", d2), (f"{t}.attn2.to_v.weight", d2)],
+                     cfg.cross_attention_dim),
+                _lin(f"{t}.attn2.to_out.0", [(f"{t}.attn2.to_out.0.weight", c)], d2),
+                _vec(f"{t}.attn2.to_out.0.bias", [(f"{t}.attn2.to_out.0.bias", c)]),
+                _lin(f"{t}.ff.net.0.proj", [(f"{t}.ff.net.0.proj.weight", 2 * ff)], c),
+                _vec(f"{t}.ff.net.0.proj.bias", [(f"{t}.ff.net.0.proj.bias", 2 * ff)]),
+                _lin(f"{t}.ff.net.2", [(f"{t}.ff.net.2.weight", c)], ff),
+                _vec(f"{t}.ff.net.2.bias", [(f"{t}.ff.net.2.bias", c)]),
+                _lin(f"{p}.proj_out", [(f"{p}.proj_out.weight", c)], c),
+                _vec(f"{p}.proj_out.bias", [(f"{p}.proj_out.bias", c)])]
+        return out
+
+    for b in blocks:
+        if b.kind == "mid":
+            E += res_entries(b.resnets[0]) + attn_entries(b.attns[0]) + res_entries(b.resnets[1])
+        else:
+            for j, r in enumerate(b.resnets):
+                E += res_entries(r)
+                if b.attns:
+                    E += attn_entries(b.attns[j])
+        if b.sampler:
+            nm = f"{b.name}.{'downsamplers' if b.kind == 'down' else 'upsamplers'}.0.conv"
+            E += [_conv(nm, b.c, b.c), _vec(nm + ".bias", [(nm + ".bias", b.c)])]
+    E += [_vec("conv_norm_out.weight", [("conv_norm_out.weight", c0)]),
+          _vec("conv_norm_out.bias", [("conv_norm_out.bias", c0)]),
+          _conv("conv_out", cfg.out_channels, c0), _vec("conv_out.bias", [("conv_out.bias", cfg.out_channels)])]
+    off = 0
+    for e in E:
+        e.off = off
+        off += (e.numel + 7) // 8 * 8
+    return E
+
+
+class ParamStore:
+    """Owns the arenas of one U-Net replica.  `train=False` (teacher): master + forward copy only."""
+
+    def __init__(self, entries: List[Entry], device, dtype, train=True):
+        self.entries = entries
+        self.by_key = {e.key: e for e in entries}
+        self.total = entries[-1].off + (entries[-1].numel + 7) // 8 * 8
+        self.dtype = dtype
+        self.train = train
+        self.master = torch.zeros(self.total, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.total, device=device, dtype=torch.float32) if train else None
+        self.w = self.master if dtype == torch.float32 else torch.zeros(self.total, device=device, dtype=dtype)
+        self.wt = torch.zeros(self.total, device=device, dtype=dtype) if train else None
+
+    # ---- views
+    def _v(self, arena, key):
+        e = self.by_key[key]
+        return arena[e.off:e.off + e.numel]
+
+    def p(self, key):
+        return self._v(self.master, key)
+
+    def g(self, key):
+        return self._v(self.grad, key)
+
+    def wv(self, key):
+        return self._v(self.w, key)
+
+    def wtv(self, key):
+        return self._v(self.wt, key)
+
+    def has(self, key):
+        return key in self.by_key
+
+    def num_logical_params(self):
+        n = 0
+        for e in self.entries:
+            m = 1
+            for s in e.logical:
+                m *= s
+            n += m * (9 if e.kind == "conv3" else 1)
+        return n
+
+    # ---- compute copies (call after every optimiser step / weight load)
+    def refresh(self):
+        for e in self.entries:
+            if e.kind == "vec":
+                continue
+            src = self.master[e.off:e.off + e.numel]
+            if self.dtype != torch.float32:
+                k.cast_permute(src, self.w[e.off:], e.numel, 1, 1, 0)
+            if self.wt is not None:
+                if e.kind == "lin":
+                    k.cast_permute(src, self.wt[e.off:], e.shape[0], 1, e.shape[1], 1)
+                else:
+                    k.cast_permute(src, self.wt[e.off:], e.shape[0], 9, e.shape[2], 2)
+
+    # ---- state dict interchange (diffusers names, pruned shapes)
+    @torch.no_grad()
+    def load_state_dict(self, sd, strict=True):
+        seen = set()
+        for e in self.entries:
+            parts = []
+            for name, rows in e.srcs:
+                if name not in sd:
+                    raise KeyError(f"missing key {name}")
+                t = sd[name].detach().to(torch.float32).cpu()
+                seen.add(name)
+                if e.kind == "conv3":
+                    assert t.dim() == 4 and t.shape[0] == rows and t.shape[1] == e.logical[1] and t.shape[2:] == (3, 3), \
+                        f"{name}: got {tuple(t.shape)}, expected ({rows},{e.logical[1]},3,3)"
+                    t = t.permute(0, 2, 3, 1)
+                elif e.kind == "lin":
+                    t = t.reshape(t.shape[0], -1)
+                    assert tuple(t.shape) == (rows, e.logical[1]), f"{name}: got {tuple(t.shape)}, expected {(rows, e.logical[1])}"
+                else:
+                    assert tuple(t.shape) == (rows,), f"{name}: got {tuple(t.shape)}, expected {(rows,)}"
+                parts.append(t)
+            t = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+            packed = torch.zeros(e.shape)
+            if e.kind == "conv3":
+                packed[:t.shape[0], :, :t.shape[3]] = t.reshape(t.shape[0], 9, t.shape[3])
+            elif e.kind == "lin":
+                packed[:t.shape[0], :t.shape[1]] = t
+            else:
+                packed[:t.shape[0]] = t
+            self.master[e.off:e.off + e.numel].copy_(packed.reshape(-1))
+        if strict:
+            extra = set(sd) - seen
+            if extra:
+                raise KeyError(f"unexpected keys in state dict: {sorted(extra)[:5]} ...")
+        self.refresh()
+
+    @torch.no_grad()
+    def state_dict(self, arena=None):
+        arena = self.master if arena is None else arena
+        out = {}
+        for e in self.entries:
+            t = arena[e.off:e.off + e.numel].detach().cpu().reshape(e.shape)
+            r0 = 0
+            for name, rows in e.srcs:
+                if e.kind == "conv3":
+                    out[name] = t[r0:r0 + rows, :, :e.logical[1]].reshape(rows, 3, 3, e.logical[1]).permute(0, 3, 1, 2).contiguous()
+                elif e.kind == "lin":
+                    w = t[r0:r0 + rows, :e.logical[1]].contiguous()
+                    out[name] = w.reshape(rows, e.logical[1], 1, 1) if name.endswith("conv_shortcut.weight") else w
+                else:
+                    out[name] = t[r0:r0 + rows].clone()
+                r0 += rows
+        return out
+
+    @torch.no_grad()
+    def init_random(self, seed=0):
+        """PyTorch-default initialisation of every logical tensor (the reference's random_init path,
+        unet_2d_conditional.py:2406-2408), generated directly in packed layout on the device."""
+        g = torch.Generator(device=self.master.device).manual_seed(seed)
+        for e in self.entries:
+            view = self.master[e.off:e.off + e.numel].view(e.shape)
+            view.zero_()
+            if e.kind == "vec":
+                n = e.logical[0]
+                if e.key.endswith(".weight") and ("norm" in e.key):
+                    view[:n] = 1.0
+                elif e.key.endswith(".bias") and ("norm" not in e.key):
+                    fan = self._fan_in_of_bias(e.key)
+                    view[:n] = (torch.rand(n, generator=g, device=view.device) * 2 - 1) / fan ** 0.5
+            elif e.kind == "lin":
+                n, kk = e.logical
+                view[:n, :kk] = (torch.rand(n, kk, generator=g, device=view.device) * 2 - 1) / kk ** 0.5
+            else:
+                co, ci = e.logical
+                view[:co, :, :ci] = (torch.rand(co, 9, ci, generator=g, device=view.device) * 2 - 1) / (9 * ci) ** 0.5
+        self.refresh()
+
+    def _fan_in_of_bias(self, key):
+        wkey = key[:-len(".bias")] + ".weight"
+        if wkey in self.by_key:
+            e = self.by_key[wkey]
+            return e.logical[1] * (9 if e.kind == "conv3" else 1)
+        for e in self.entries:          # fused projections
+            if any(n == wkey for n, _ in e.srcs):
+                return e.logical[1]
+        return 1

@@ -1,0 +1,255 @@
+"""The bilevel fine-tune / unlearn step on the MI355X engine: forward diffusion, teacher + student passes, the four loss
+heads, hand-written backward, data-parallel gradient reduction and the two fused AdamW optimisers.
+
+Reference arithmetic:
+  main step    pdm/training/trainer.py:2403-2488  (DDPM min-SNR(gamma) + w_block * block-feature MSE + w_dist * output MSE)
+  upper step   trainer.py:2904-3001               (ESD-style negative guidance target e_u - (e_c - e_u))
+  loop cadence trainer.py:2769-2816               (upper step every `upper_step_freq` iterations, its own AdamW + LR)
+  optimisers   trainer.py:265-284, 2695-2717      (torch.optim.AdamW semantics), LR trainer.py:436-443, 2666-2674
+  DDP          trainer.py:117-129, 2782, 2808     (gradient mean over ranks)
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from .. import _pdmk as k
+from ..models.unet.spec import pad8
+from ..utils.metric_utils import alphas_cumprod_sd, min_snr_weight_table
+
+BLOCK_KEYS = ("d0", "d1", "d2", "d3", "m", "u0", "u1", "u2", "u3")
+
+
+class FusedAdamW:
+    """torch.optim.AdamW over the flat fp32 arena, one kernel launch (pdmk_adamw)."""
+
+    def __init__(self, store, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, warmup_steps=0, sched_mult=1):
+        dev = store.master.device
+        self.store = store
+        self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(store.master)
+        self.v = torch.zeros_like(store.master)
+        self.lr_dev = torch.zeros(1, device=dev)
+        self.bc_dev = torch.zeros(2, device=dev)
+        self.t = 0                     # optimiser steps taken
+        self.sched_k = 0               # scheduler.step() calls (accelerate steps it `sched_mult`=W times per opt step)
+        self.warmup = warmup_steps     # already multiplied by W by the caller (trainer.py:436-443)
+        self.sched_mult = sched_mult
+
+    def current_lr(self):
+        if self.warmup > 0:
+            return self.base_lr * min(1.0, self.sched_k / float(self.warmup))
+        return self.base_lr
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        self.t += 1
+        lr = self.current_lr()
+        self.lr_dev.fill_(lr)
+        self.bc_dev.copy_(torch.tensor([1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t]))
+        s = self.store
+        k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
+                self.wd, self.bc_dev, grad_scale, zero_grad)
+        self.sched_k += self.sched_mult
+        s.refresh()
+        return lr
+
+    def state_dict(self):
+        return {"m": self.m.cpu(), "v": self.v.cpu(), "t": self.t, "sched_k": self.sched_k}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        self.t, self.sched_k = sd["t"], sd["sched_k"]
+
+
+class GradReducer:
+    """Data-parallel mean of the flat gradient arena over RCCL (`nccl` backend) / gloo.
+
+    Reference = DDP's bucketed all-reduce inside accelerator.backward (trainer.py:2782, 2808).  Here the arena is
+    reduced in `bucket_mb` slices issued on a side stream as soon as the backward pass has produced them (the arena is
+    laid out in forward order, so the tail is final first); the division by world size is folded into AdamW."""
+
+    def __init__(self, store, bucket_mb=64):
+        self.store = store
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.bucket = bucket_mb * (1 << 20) // 4
+        self.stream = torch.cuda.Stream() if (self.world > 1 and store.master.is_cuda) else None
+        self.handles = []
+        self.next_hi = store.total
+
+    def begin(self):
+        self.next_hi = self.store.total
+        self.handles = []
+
+    def ready_down_to(self, lo):
+        """Everything in [lo, total) is final: launch whole buckets from the tail (called from the backward tape)."""
+        if self.world == 1:
+            return
+        lo = max(lo, 0)
+        while self.next_hi - lo >= self.bucket:
+            self._launch(self.next_hi - self.bucket, self.next_hi)
+            self.next_hi -= self.bucket
+
+    def _launch(self, lo, hi):
+        g = self.store.grad[lo:hi]
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+
+    def finish(self):
+        if self.world == 1:
+            return 1.0
+        if self.next_hi > 0:
+            self._launch(0, self.next_hi)
+            self.next_hi = 0
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return 1.0 / self.world
+
+
+class BilevelStepper:
+    def __init__(self, student, teacher, *, w_diff=1.0, w_dist=2.0, w_block=0.1, snr_gamma=5.0, up_w_diff=0.0,
+                 up_w_dist=1.0, up_w_block=0.0, prediction_type="v_prediction", lr=1e-6, upper_lr=5e-6,
+                 betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, warmup_steps=0, upper_warmup_steps=0,
+                 bilevel=True, bucket_mb=64):
+        if prediction_type not in ("v_prediction", "epsilon"):
+            raise ValueError(f"Unknown prediction type {prediction_type}")        # trainer.py:2445
+        self.student, self.teacher = student, teacher
+        self.dev = student.device
+        self.w = dict(diff=w_diff, dist=w_dist, block=w_block, up_diff=up_w_diff, up_dist=up_w_dist, up_block=up_w_block)
+        self.prediction_type = prediction_type
+        ac = alphas_cumprod_sd()
+        self.sqrt_acp = ac.sqrt().contiguous().to(self.dev)
+        self.sqrt_1macp = (1.0 - ac).sqrt().contiguous().to(self.dev)
+        self.snr_w = (min_snr_weight_table(ac, snr_gamma, prediction_type == "v_prediction") if snr_gamma is not None
+                      else torch.ones(1000)).to(self.dev)
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = world
+        self.opt = FusedAdamW(student.store, lr, betas, eps, weight_decay, warmup_steps * world, world)
+        self.upper_opt = FusedAdamW(student.store, upper_lr, betas, eps, weight_decay, upper_warmup_steps * world,
+                                    world) if bilevel else None
+        self.reducer = GradReducer(student.store, bucket_mb)
+        self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused)
+
+    # ------------------------------------------------------------------ pieces
+    def _diffuse(self, latents, noise, timesteps, want_target):
+        B, C, H, W = latents.shape
+        cp = pad8(C)
+        dt = self.student.dtype
+        noisy = torch.empty((B * H * W, cp), device=self.dev, dtype=dt)
+        target = torch.empty((B * H * W, cp), device=self.dev, dtype=torch.float32) if want_target else None
+        k.add_noise_velocity(latents, noise, timesteps, self.sqrt_acp, self.sqrt_1macp, noisy, target, B, C, H * W, cp)
+        if want_target and self.prediction_type == "epsilon":
+            k.nchw_to_nhwc(noise, target, B, C, H * W, cp)
+        return noisy, target
+
+    def _ehs2d(self, e):
+        return e.to(self.dev).to(self.student.dtype).reshape(e.shape[0] * e.shape[1], e.shape[2]).contiguous()
+
+    def _block_loss(self, acts_s, acts_t, B, weight, t_row0=0, seed=True):
+        """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds."""
+        for key in BLOCK_KEYS:
+            a, b = acts_s[key], acts_t[key]
+            M, C = a.t.shape
+            bt = b.t[t_row0:t_row0 + M]
+            n = len(BLOCK_KEYS) * M * C
+            k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
+            if seed and weight > 0:
+                a.g = torch.empty_like(a.t)
+                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
+
+    def _backward_and_reduce(self):
+        self.reducer.begin()
+        self.student.engine.grad_ready_cb = self.reducer.ready_down_to
+        self.student.engine.backward()
+        return self.reducer.finish()
+
+    # ------------------------------------------------------------------ steps
+    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True):
+        """latents/noise [B,4,H,W] fp32 (latents already x scaling_factor), timesteps int64 [B], prompt_embeds [B,T,ctx].
+        Returns the device tensor [diff, dist, block, 0] (float64); total = w_diff*diff + w_block*block + w_dist*dist."""
+        B, C, H, W = latents.shape
+        w = self.w
+        need_teacher = w["block"] > 0 or w["dist"] > 0
+        noisy, target = self._diffuse(latents, noise, timesteps, True)
+        ehs = self._ehs2d(prompt_embeds)
+        self.losses.zero_()
+        if need_teacher:
+            pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
+        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        wb = self.snr_w[timesteps].contiguous()
+        HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
+        k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
+        if w["dist"] > 0:
+            k.mse_fwd(pred.t, pred_t.t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
+        if backward:
+            pred.g = torch.zeros_like(pred.t)
+            k.mse_bwd(pred.t, target, wb, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["diff"] / n, False)
+            if w["dist"] > 0:
+                k.mse_bwd(pred.t, pred_t.t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
+        if w["block"] > 0:
+            self._block_loss(acts, acts_t, B, w["block"], seed=backward)
+        self.last_pred = pred
+        if backward:
+            self._gscale = self._backward_and_reduce()
+        return self.losses
+
+    def upper_step(self, latents, noise, timesteps, prompt_embeds, empty_prompt_embeds, backward=True):
+        """Concept-suppression objective: w * mse(student(x_t, c), e_u - (e_c - e_u)) with the teacher's cond / uncond
+        predictions computed as ONE batch of 2B."""
+        B, C, H, W = latents.shape
+        w = self.w
+        noisy, _ = self._diffuse(latents, noise, timesteps, False)
+        ehs = self._ehs2d(prompt_embeds)
+        ehs2 = torch.cat([ehs, self._ehs2d(empty_prompt_embeds)], 0)
+        noisy2 = torch.cat([noisy, noisy], 0)
+        t2 = torch.cat([timesteps, timesteps], 0)
+        self.losses.zero_()
+        pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
+        M = B * H * W
+        e_c, e_u = pred_t.t[:M], pred_t.t[M:]
+        k.axpby(e_c, e_u, -1.0, 2.0)               # e_u <- 2 e_u - e_c  == e_u - (e_c - e_u)
+        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        cp, n = pred.t.shape[1], M * C
+        k.mse_fwd(pred.t, e_u, None, self.losses, 1, B, H * W, C, cp, cp, 1.0 / n)
+        if backward:
+            pred.g = torch.zeros_like(pred.t)
+            k.mse_bwd(pred.t, e_u, None, pred.g, B, H * W, C, cp, cp, cp, 2.0 * w["up_dist"] / n, False)
+        if w["up_block"] > 0:
+            # the reference's teacher hooks hold the LAST teacher call (the unconditional one), trainer.py:2951-2954
+            self._block_loss_rows(acts, acts_t, B, w["up_block"], backward)
+        self.last_pred = pred
+        if backward:
+            self._gscale = self._backward_and_reduce()
+        return self.losses
+
+    def _block_loss_rows(self, acts_s, acts_t, B, weight, seed):
+        for key in BLOCK_KEYS:
+            a, b = acts_s[key], acts_t[key]
+            M, C = a.t.shape
+            bt = b.t[M:2 * M]
+            n = len(BLOCK_KEYS) * M * C
+            k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
+            if seed:
+                a.g = torch.empty_like(a.t)
+                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
+
+    def optimizer_step(self, upper=False, max_grad_norm=None):
+        opt = self.upper_opt if upper else self.opt
+        scale = self._gscale
+        if max_grad_norm is not None:
+            ss = torch.zeros(1, device=self.dev, dtype=torch.float64)
+            k.sumsq(self.student.store.grad, self.student.store.total, ss, 0)
+            norm = math.sqrt(float(ss.item())) * scale
+            scale *= min(1.0, max_grad_norm / (norm + 1e-6))
+        return opt.step(grad_scale=scale, zero_grad=True)
+
+    def total(self, losses, upper=False):
+        d, s, b = (float(x) for x in losses[:3].tolist())
+        w = self.w
+        if upper:
+            return w["up_dist"] * s + w["up_block"] * b, 0.0, s, b
+        return w["diff"] * d + w["block"] * b + w["dist"] * s, d, s, b
