@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — bilevel train-step images/sec @512^2 on the pruned SD-2.1 U-Net (BASELINE.json metric), N GPUs of one node.
+
+One "step" = one iteration of the bilevel loop (trainer.py:2769-2816): main step (teacher fwd, student fwd+bwd, three
+loss heads, grad all-reduce, AdamW + weight refresh) and, on every 10th iteration, the upper step (teacher cond+uncond
+fwd as one 2B batch, student fwd+bwd, negative-guidance loss, all-reduce, upper AdamW).  Synthetic (latent, noise,
+timestep, prompt-embed) inputs are resident in HBM before the timed region; weights are random-init SD-2.1 shapes.
+
+Prints ONE JSON line (rank 0).  Extra keys: roofline (dominant kernel, HIP-event timed), cpu_baseline (oracle on host
+cores, N=1 only), breakdown.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "unlearn-ft_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    p.add_argument("--budget", type=float, default=0.55, help="student MACs / teacher MACs (reference 'Pruning Ratio')")
+    p.add_argument("--latent", type=int, default=64, help="latent side (64 = 512^2 images)")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--upper_freq", type=int, default=10)
+    p.add_argument("--tiny", action="store_true", help="tiny topology (debug only; result is NOT the benchmark)")
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_roofline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(budget, latent, tiny):
+    """The oracle's main step (B=1, fp32) on the host cores: reported baseline, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pdm_ref import arch as oarch, weights as oweights, step as ostep
+    from pdm_ref.config import UNetConfig as OCfg
+    from pdm.models.unet.spec import UNetConfig, arch_vector_for_budget
+    ocfg = OCfg.tiny() if tiny else OCfg.sd21()
+    cfg = UNetConfig.tiny() if tiny else UNetConfig.sd21()
+    T = 13 if tiny else 77
+    cores = torch.get_num_threads()
+    dense = oweights.init_dense_state_dict(ocfg, seed=0)
+    av = arch_vector_for_budget(cfg, budget, hw=latent, ctx_len=T)[0]
+    psd, info = oweights.prune_state_dict(dense, ocfg, av)
+    P = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+    g = torch.Generator().manual_seed(43)
+    lat, noise = torch.randn(1, 4, latent, latent, generator=g), torch.randn(1, 4, latent, latent, generator=g)
+    t, ehs = torch.tensor([500]), torch.randn(1, T, ocfg.cross_attention_dim, generator=g)
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-6, weight_decay=0.0)
+    t0 = time.time()
+    loss = ostep.main_step_loss((P, info), (dense, oweights.dense_info(ocfg)), ocfg, ostep.alphas_cumprod(), lat, noise,
+                                t, ehs)[0]
+    loss.backward()
+    opt.step()
+    dt_ = time.time() - t0
+    return {"value": round(1.0 / dt_, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"1 main step (dense teacher fwd + budget-{budget} student fwd/bwd + 3 loss heads + AdamW), B=1, "
+                      f"{latent}x{latent} latent, fp32, pure-torch CPU oracle; {dt_:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from pdm import _pdmk as k
+    from pdm.models.unet.spec import UNetConfig, arch_vector_for_budget, plan_macs
+    from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+    from pdm.training.bilevel import BilevelStepper
+
+    cfg = UNetConfig.tiny() if a.tiny else UNetConfig.sd21()
+    T = 13 if a.tiny else 77
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    av, ratio, keep = arch_vector_for_budget(cfg, a.budget, hw=a.latent, ctx_len=T)
+    teacher = UNet2DConditionModelPruned(cfg, None, dev, dtype, train=False, seed=0)
+    student = UNet2DConditionModelPruned(cfg, av, dev, dtype, train=True, init=False)
+    student.load_dense_or_pruned(teacher.state_dict())
+    # shipped bilevel config: weights 1.0 / 2.0 / 0.1, snr_gamma 5, upper distillation 1.0, lr 1e-6 / 5e-6
+    st = BilevelStepper(student, teacher, w_diff=1.0, w_dist=2.0, w_block=0.1, snr_gamma=5.0, up_w_dist=1.0,
+                        lr=1e-6, upper_lr=5e-6, warmup_steps=250, upper_warmup_steps=250)
+    Tm = plan_macs(cfg, teacher.blocks, a.latent, T)[0]
+    Sm = plan_macs(cfg, student.blocks, a.latent, T)[0]
+
+    B = a.batch
+    g = torch.Generator(device=dev).manual_seed(43 + rank)
+    nb = 4   # a few distinct resident batches, cycled
+    data = [dict(lat=torch.randn(B, 4, a.latent, a.latent, device=dev, generator=g),
+                 noise=torch.randn(B, 4, a.latent, a.latent, device=dev, generator=g),
+                 t=torch.randint(0, 1000, (B,), device=dev, generator=g),
+                 ehs=torch.randn(B, T, cfg.cross_attention_dim, device=dev, generator=g)) for _ in range(nb)]
+    empty = torch.randn(1, T, cfg.cross_attention_dim, device=dev, generator=g).expand(B, -1, -1).contiguous()
+
+    def main_iter(i):
+        d = data[i % nb]
+        st.main_step(d["lat"], d["noise"], d["t"], d["ehs"])
+        st.optimizer_step(upper=False)
+
+    def upper_iter(i):
+        d = data[(i + 1) % nb]
+        st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], empty)
+        st.optimizer_step(upper=True)
+
+    def bilevel_iter(i):
+        main_iter(i)
+        if (i + 1) % a.upper_freq == 0:
+            upper_iter(i)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        main_iter(i)
+    if a.warmup > 0:
+        upper_iter(0)         # untimed: warm the allocator for the upper step too
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        bilevel_iter(i)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # ---- untimed extras on rank 0: per-phase times, roofline of the dominant kernel
+    extras = {}
+    if rank == 0:
+        def timed(fn, n):
+            torch.cuda.synchronize()
+            s = time.perf_counter()
+            for j in range(n):
+                fn(j)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - s) / n
+        if world == 1:
+            extras["ms_main_step"] = round(timed(main_iter, 3) * 1e3, 2)
+            extras["ms_upper_step"] = round(timed(upper_iter, 2) * 1e3, 2)
+        n_upper = sum(1 for i in range(a.steps) if (i + 1) % a.upper_freq == 0)
+        flop_main = 2.0 * (Tm + 3 * Sm) * B
+        flop_upper = 2.0 * (2 * Tm + 3 * Sm) * B
+        extras["model_tflops_per_gpu"] = round((a.steps * flop_main + n_upper * flop_upper) / el / 1e12, 2)
+    roof = None
+    if rank == 0 and not a.no_roofline and world == 1:
+        k.PROFILE = []
+        main_iter(0)
+        torch.cuda.synchronize()
+        prof, k.PROFILE = k.PROFILE, None
+        agg = {}
+        for kind, flops, e0, e1, shp in prof:
+            ms = e0.elapsed_time(e1)
+            r = agg.setdefault(kind, [0.0, 0.0, 0])
+            r[0] += flops
+            r[1] += ms
+            r[2] += 1
+        dom = max(agg.items(), key=lambda kv: kv[1][1])
+        names = {(0, 0): "igemm<rowk,rowk> (linear fwd/dgrad)", (1, 0): "igemm<conv,rowk> (conv3x3 fwd/dgrad)",
+                 (2, 1): "igemm<colk,colk> (linear wgrad)", (2, 2): "igemm<colk,colk_conv> (conv3x3 wgrad)"}
+        ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
+        peak = 2500.0 if a.dtype == "bf16" else 157.3
+        roof = {"bound": "mfma", "kernel": f"{dom[0][0]} {names[(dom[0][1], dom[0][2])]}",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None, "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
+                "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),
+                "all_gemm_kinds": {f"{kd[0]} {names[(kd[1], kd[2])]}": {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
+                                                                         "ms": round(v[1], 2), "launches": v[2]}
+                                   for kd, v in agg.items()}}
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        del data
+        torch.cuda.empty_cache()
+        cpu = cpu_baseline(a.budget, a.latent, a.tiny)
+
+    if rank == 0:
+        value = a.steps * B * world / el
+        out = {"metric": "bilevel train-step images/sec @512^2 pruned-SD2.1", "value": round(value, 3),
+               "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[1] model+batch (MAC-budget-{a.budget} SD-2.1 student [ratio "
+                                      f"{ratio:.3f}, {Sm / 1e9:.1f} GMAC/img] + dense teacher [{Tm / 1e9:.1f} GMAC/img], "
+                                      f"B={B}/GPU, {a.latent}x{a.latent} latents = {a.latent * 8}^2 px, losses 1.0 ddpm(min-SNR 5) "
+                                      f"+ 2.0 distill + 0.1 block) under the bilevel cadence of configs[2] (upper "
+                                      f"concept-suppression step every {a.upper_freq}th iteration, second AdamW)"
+                                      + (" [TINY DEBUG TOPOLOGY - not the benchmark]" if a.tiny else ""),
+                          "global_batch": B * world, "parallelism": f"dp{world}", "student_params": student.num_parameters(),
+                          "weights": "random-init"},
+               "roofline": roof, "cpu_baseline": cpu, "extras": extras}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

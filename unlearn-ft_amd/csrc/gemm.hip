@@ -123,7 +123,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g) {
         b_ci = col - b_tap * cg.ci;
     }
 
+    // Loads are always issued from a valid address (the operand base when predicated off) and the zero-fill is applied
+    // when the registers are written to LDS, AFTER the MFMAs of the current tile: a data select right behind the load
+    // would make the compiler wait for the load (vmcnt(0)) before the MFMAs and expose the full memory latency.
     uint4 ra[2], rb[2];
+    bool pa[2], pb[2];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
     auto load_tiles = [&](int kt) {
@@ -132,37 +136,43 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g) {
         if (AMODE == PDMK_A_ROWK) {
             const int k = k0 + kc;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) ra[s] = (a_ok[s] && k < g.K) ? ld16(a_row[s] + k) : zero4;
+            for (int s = 0; s < 2; ++s) {
+                pa[s] = a_ok[s] && k < g.K;
+                ra[s] = ld16(pa[s] ? a_row[s] + k : Ap);
+            }
         } else if (AMODE == PDMK_A_CONV) {
             const int k = k0 + kc;
             const int tap = k / cg.ci, ci = k - tap * cg.ci;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                ra[s] = zero4;
-                if (a_ok[s] && k < g.K) {
-                    const long px = conv_src_pixel(cg, a_b[s], a_oy[s], a_ox[s], tap);
-                    if (px >= 0) ra[s] = ld16(Ap + px * cg.ld + ci);
-                }
+                const long px = (a_ok[s] && k < g.K) ? conv_src_pixel(cg, a_b[s], a_oy[s], a_ox[s], tap) : -1;
+                pa[s] = px >= 0;
+                ra[s] = ld16(pa[s] ? Ap + px * cg.ld + ci : Ap);
             }
         } else {
             const int col = m0 + cmc;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int kr = k0 + ckr + TC::KROW_STEP * s;
-                ra[s] = (kr < g.K && col < g.M) ? ld16(Ap + (long)kr * g.lda + col) : zero4;
+                pa[s] = kr < g.K && col < g.M;
+                ra[s] = ld16(pa[s] ? Ap + (long)kr * g.lda + col : Ap);
             }
         }
         // ---- B
         if (BMODE == PDMK_B_ROWK) {
             const int k = k0 + kc;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) rb[s] = (b_ok[s] && k < g.K) ? ld16(b_row[s] + k) : zero4;
+            for (int s = 0; s < 2; ++s) {
+                pb[s] = b_ok[s] && k < g.K;
+                rb[s] = ld16(pb[s] ? b_row[s] + k : Bp);
+            }
         } else if (BMODE == PDMK_B_COLK) {
             const int col = n0 + cmc;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int kr = k0 + ckr + TC::KROW_STEP * s;
-                rb[s] = (kr < g.K && col < g.N) ? ld16(Bp + (long)kr * g.ldb + col) : zero4;
+                pb[s] = kr < g.K && col < g.N;
+                rb[s] = ld16(pb[s] ? Bp + (long)kr * g.ldb + col : Bp);
             }
         } else {
             const int col = n0 + cmc;
@@ -170,14 +180,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int kr = k0 + ckr + TC::KROW_STEP * s;
-                rb[s] = zero4;
+                long px = -1;
                 if (kr < g.K && col < g.N) {
                     const int b = kr / hw;
                     const int rem = kr - b * hw;
                     const int oy = rem / cg.wo, ox = rem - oy * cg.wo;
-                    const long px = conv_src_pixel(cg, b, oy, ox, b_tap);
-                    if (px >= 0) rb[s] = ld16(Bp + px * cg.ld + b_ci);
+                    px = conv_src_pixel(cg, b, oy, ox, b_tap);
                 }
+                pb[s] = px >= 0;
+                rb[s] = ld16(pb[s] ? Bp + px * cg.ld + b_ci : Bp);
             }
         }
     };
@@ -185,6 +196,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g) {
     auto store_tiles = [&](int buf) {
         T* As = reinterpret_cast<T*>(smem[buf][0]);
         T* Bs = reinterpret_cast<T*>(smem[buf][1]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (!pa[s]) ra[s] = zero4;
+            if (!pb[s]) rb[s] = zero4;
+        }
         if (AMODE == PDMK_A_COLK) {
 #pragma unroll
             for (int s = 0; s < 2; ++s)

@@ -102,9 +102,13 @@ def _chk(rc, name):
         raise PdmkError(f"{name} failed with status {rc}")
 
 
+PROFILE = None   # bench.py sets this to a list: every gemm launch is then bracketed by HIP events on the launch stream
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
-         a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0):
-    """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None."""
+         a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
+         macs=None):
+    """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
     g.A, g.B, g.C = _p(A), _p(B), _p(Cout)
     g.bias, g.rowvec, g.R = _p(bias), _p(rowvec), _p(R)
@@ -116,7 +120,15 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
         (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
     g.dtype = dt(A) if dtype is None else dtype
     g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
+    if PROFILE is None:
+        _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+    e1.record()
+    kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode)
+    PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
 
 
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps, silu):

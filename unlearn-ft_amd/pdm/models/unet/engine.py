@@ -78,9 +78,10 @@ class UNetEngine:
         y = self._empty(M, Np, torch.float32 if out_f32 else None)
         k.gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np,
                bias=P.p(bias) if bias else None, R=residual.t if residual else None,
-               ldr=_ld(residual.t) if residual else 0, out_f32=out_f32)
+               ldr=_ld(residual.t) if residual else 0, out_f32=out_f32, macs=M * e.logical[0] * e.logical[1])
+        lmacs = M * e.logical[0] * e.logical[1]
         if self.count_macs:
-            self.macs += M * e.logical[0] * e.logical[1]
+            self.macs += lmacs
         out = Act(y)
         if self.train:
             def bwd():
@@ -91,10 +92,10 @@ class UNetEngine:
                     dy = dyc
                 if x.rg:
                     dx, acc = self._grad_into(x, M, Kp)
-                    k.gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc)
+                    k.gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc, macs=lmacs)
                 sk = self._splitk(Np, Kp, M, 32)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
-                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t))
+                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
                 if bias:
                     k.colsum(dy, P.g(bias), M, Np, _ld(dy), accumulate=True)
                 if residual is not None:
@@ -114,9 +115,11 @@ class UNetEngine:
         k.gemm(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
                rowvec=rowvec.t if rowvec is not None else None, rows_per_b=Ho * Wo,
-               R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0)
+               R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
+               macs=M * e.logical[0] * e.logical[1] * 9)
+        lmacs = M * e.logical[0] * e.logical[1] * 9
         if self.count_macs:
-            self.macs += M * e.logical[0] * e.logical[1] * 9
+            self.macs += lmacs
         out = Act(y)
         if self.train:
             def bwd():
@@ -126,7 +129,7 @@ class UNetEngine:
                     if mode == 2:
                         tmp = self._empty(M, Cip)
                         k.gemm(dy, P.wtv(key + ".weight"), tmp, M, Cip, 9 * Cop, 0, 9 * Cop, Cip, a_mode=k.A_CONV,
-                               conv=(B, Ho, Wo, Cop, Ho, Wo, 0, ldy))
+                               conv=(B, Ho, Wo, Cop, Ho, Wo, 0, ldy), macs=lmacs)
                         pooled = self._empty(B * Hi * Wi, Cip)
                         k.pool2x2_sum(tmp, pooled, B, Hi, Wi, Cip)
                         self._give(x, pooled)
@@ -134,11 +137,11 @@ class UNetEngine:
                         dx, acc = self._grad_into(x, B * Hi * Wi, Cip)
                         k.gemm(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
                                a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
-                               accumulate=acc)
+                               accumulate=acc, macs=lmacs)
                 sk = self._splitk(Cop, 9 * Cip, M, 32)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
                        b_mode=k.B_COLK_CONV, conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), out_f32=True, splitk=sk,
-                       accumulate=(sk == 1), dtype=k.dt(x.t))
+                       accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
                 if rowvec is not None:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
                     dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)

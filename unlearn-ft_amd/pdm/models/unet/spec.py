@@ -208,3 +208,66 @@ def apply_arch_vector(cfg: UNetConfig, arch_vector) -> List[BlockSpec]:
                 assert masks[0].any() and masks[1].any(), "attention with zero heads (blocks.py:165 asserts > 0)"
     assert not wq and not dq
     return blocks
+
+
+def plan_macs(cfg: UNetConfig, blocks, hw: int, ctx_len: int):
+    """Exact forward multiply-accumulates per image of the (pruned) plan at latent side `hw`: 3x3/1x1 convs, every
+    Linear, QK^T and PV of both attentions (logical, un-padded widths).  Returns (total, by_kind dict)."""
+    G = cfg.norm_num_groups
+    by = {"conv3x3": 0, "conv1x1": 0, "linear": 0, "sdpa": 0}
+    c0 = cfg.block_out_channels[0]
+    by["conv3x3"] += hw * hw * 9 * cfg.in_channels * c0
+    by["linear"] += c0 * cfg.temb_dim + cfg.temb_dim * cfg.temb_dim
+    side = hw
+
+    def res(r, px):
+        if r.dropped:
+            return
+        ci = r.inner(G)
+        by["conv3x3"] += px * 9 * (r.cin * ci + ci * r.cout)
+        by["linear"] += cfg.temb_dim * ci
+        if r.cin != r.cout:
+            by["conv1x1"] += px * r.cin * r.cout
+
+    def att(a, px):
+        if a.dropped:
+            return
+        c, d1, d2, ff = a.c, a.h1() * 64, a.h2() * 64, a.ff(cfg.ff_gate_width)
+        by["linear"] += px * (2 * c * c + 4 * c * d1 + 2 * c * d2 + 3 * c * ff) + 2 * ctx_len * cfg.cross_attention_dim * d2
+        by["sdpa"] += 2 * px * px * d1 + 2 * px * ctx_len * d2
+
+    for b in blocks:
+        px = side * side
+        if b.kind == "mid":
+            res(b.resnets[0], px); att(b.attns[0], px); res(b.resnets[1], px)
+            continue
+        for j, r in enumerate(b.resnets):
+            res(r, px)
+            if b.attns:
+                att(b.attns[j], px)
+        if b.sampler:
+            side = side // 2 if b.kind == "down" else side * 2
+            by["conv3x3"] += side * side * 9 * b.c * b.c
+    by["conv3x3"] += hw * hw * 9 * c0 * cfg.out_channels
+    return sum(by.values()), by
+
+
+def arch_vector_for_budget(cfg: UNetConfig, budget, hw=64, ctx_len=77, seed=0, tol=0.004):
+    """Random arch vector (get_random_arch_vector, all depth gates kept) whose MAC ratio student/teacher - the
+    reference's "Pruning Ratio" (trainer.py:2183) - is `budget`, found by bisection on the per-gate keep ratio."""
+    dense, _ = plan_macs(cfg, build_blocks(cfg), hw, ctx_len)
+    lo, hi = 0.05, 1.0
+    best = None
+    for _ in range(24):
+        mid = 0.5 * (lo + hi)
+        av = get_random_arch_vector(mid, gate_structure(cfg), torch.Generator().manual_seed(seed))
+        ratio = plan_macs(cfg, apply_arch_vector(cfg, av), hw, ctx_len)[0] / dense
+        if best is None or abs(ratio - budget) < abs(best[1] - budget):
+            best = (av, ratio, mid)
+        if abs(ratio - budget) <= tol:
+            break
+        if ratio < budget:
+            lo = mid
+        else:
+            hi = mid
+    return best

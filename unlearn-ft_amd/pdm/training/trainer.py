@@ -1,0 +1,292 @@
+"""Trainer classes with the reference's names and call contract (pdm/training/trainer.py:2116-3016), running on the
+MI355X engine:  UnetFineTuner(config).train(),  BilevelUnetFineTuner(config).train(),  NudityBilevelUnetFineTuner.
+
+Differences that are deliberate:
+ * `step(batch)` / `upper_step(batch)` return the reference's 4-tuple (loss, diff_loss, distillation_loss, block_loss)
+   but ALSO run the hand-written backward (there is no autograd graph to hand to accelerator.backward);
+ * no accelerate / wandb: ranks come from torch.distributed (RCCL), metrics go to <logging_dir>/metrics.jsonl with the
+   reference's key names (trainer.py:2819-2834) and are read back asynchronously (no per-step .item() syncs);
+ * batches carry `latents` (VAE encode is SURVEY 8f row N1, not built yet); `--synthetic` produces seeded batches;
+ * torch.autograd.set_detect_anomaly (scripts/aptp/*.py:21) is not reproduced.
+"""
+import glob
+import json
+import logging
+import os
+import pickle
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..models.unet.spec import UNetConfig, arch_vector_for_budget
+from ..models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+from .bilevel import BilevelStepper
+
+logger = logging.getLogger("pdm.trainer")
+
+
+def _cfg(config, path, default=None):
+    cur = config
+    for part in path.split("."):
+        if cur is None:
+            return default
+        cur = cur.get(part) if isinstance(cur, dict) else getattr(cur, part, None)
+    return default if cur is None else cur
+
+
+class SyntheticBatches:
+    """Seeded (latent, prompt-embed) batches of the collate_fn schema (pdm/utils/data_utils.py:286-312) minus pixels."""
+
+    def __init__(self, batch_size, hw, ctx_len, ctx_dim, seed, device, length=1 << 30):
+        self.bs, self.hw, self.T, self.D, self.device, self.length = batch_size, hw, ctx_len, ctx_dim, device, length
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.empty = torch.randn(1, ctx_len, ctx_dim, generator=torch.Generator().manual_seed(1234)).to(device)
+
+    def __len__(self):
+        return self.length
+
+    def __iter__(self):
+        for _ in range(self.length):
+            yield {"latents": torch.randn(self.bs, 4, self.hw, self.hw, device=self.device, generator=self.gen),
+                   "prompt_embeds": torch.randn(self.bs, self.T, self.D, device=self.device, generator=self.gen),
+                   "empty_prompt_embeds": self.empty.expand(self.bs, -1, -1).contiguous()}
+
+
+class Trainer:
+    bilevel = False
+
+    def __init__(self, config, train_dataloader=None, upper_dataloader=None):
+        self.config = config
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        if not torch.cuda.is_available():
+            raise RuntimeError("the MI355X trainer needs a GPU (no CPU fallback for the hot path)")
+        torch.cuda.set_device(local)
+        self.device = torch.device("cuda", local)
+        self.logging_dir = _cfg(config, "training.logging.logging_dir", _cfg(config, "logging_dir", "logs"))
+        self.global_step = 0
+        self.init_weight_dtype()
+        self.init_models()
+        self.init_optimizer()
+        self.train_dataloader = train_dataloader or self.init_dataloader(upper=False)
+        self.upper_dataloader = (upper_dataloader or self.init_dataloader(upper=True)) if self.bilevel else None
+        self.rng = torch.Generator(device=self.device).manual_seed(int(_cfg(config, "seed", 43)) + self.rank)
+
+    # ---- trainer.py:516-527: student master weights fp32; bf16 compute under mixed precision
+    def init_weight_dtype(self):
+        mp = _cfg(self.config, "mixed_precision", None) or _cfg(self.config, "training.mixed_precision", None)
+        self.weight_dtype = {"bf16": torch.bfloat16, "no": torch.float32, None: torch.float32}.get(mp)
+        if self.weight_dtype is None:
+            raise ValueError(f"mixed_precision={mp!r} is not supported on this build (use bf16 or no)")
+
+    # ---- trainer.py:2122-2198
+    def init_models(self):
+        c = self.config
+        ucfg = UNetConfig.tiny() if _cfg(c, "tiny", False) else UNetConfig.sd21()
+        self.unet_config = ucfg
+        ckpt = _cfg(c, "pruning_ckpt_dir")
+        arch = None
+        if ckpt and os.path.exists(os.path.join(ckpt, "quantizer_embeddings.pt")):
+            emb = torch.load(os.path.join(ckpt, "quantizer_embeddings.pt"), map_location="cpu")
+            arch = emb[int(_cfg(c, "expert_id", 0)) % emb.shape[0]][None]         # trainer.py:2159-2161
+        elif ckpt and os.path.exists(os.path.join(ckpt, "arch_vector.pt")):
+            arch = torch.load(os.path.join(ckpt, "arch_vector.pt"), map_location="cpu")
+        else:
+            res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
+            arch, ratio, _ = arch_vector_for_budget(ucfg, float(_cfg(c, "keep_ratio", 0.55)), hw=res)
+            logger.info("no pruning checkpoint: random arch vector at MAC budget %.3f", ratio)
+        self.arch_vector = arch
+        pm = _cfg(c, "model.prediction_model", {})
+        root = _cfg(c, "pretrained_model_name_or_path")
+        local = bool(root) and os.path.isdir(os.path.join(root, "unet"))
+        kw = dict(unet_config=ucfg, torch_dtype=self.weight_dtype, device=self.device,
+                  down_block_types=pm.get("unet_down_blocks"), up_block_types=pm.get("unet_up_blocks"),
+                  gated_ff=pm.get("gated_ff", True), ff_gate_width=pm.get("ff_gate_width", 32))
+        self.teacher_model = UNet2DConditionModelPruned.from_pretrained(root if local else None, subfolder="unet",
+                                                                        arch_vector=None, random_init=not local,
+                                                                        train=False, seed=0, **kw)
+        self.prediction_model = UNet2DConditionModelPruned.from_pretrained(
+            root if local else None, subfolder="unet", arch_vector=arch,
+            random_init=bool(pm.get("random_init", False)) or not local, train=True, seed=0, **kw)
+        if not local:      # same dense initialisation sliced by the arch vector, like load-then-prune
+            self.prediction_model.load_dense_or_pruned(self.teacher_model.state_dict())
+        from ..models.unet.spec import plan_macs
+        res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
+        tm = plan_macs(ucfg, self.teacher_model.blocks, res, 77)[0]
+        sm = plan_macs(ucfg, self.prediction_model.blocks, res, 77)[0]
+        logger.info("Teacher MACs %.1f G, student MACs %.1f G, Pruning Ratio %.3f", tm / 1e9, sm / 1e9, sm / tm)
+
+    # ---- trainer.py:2233-2250, 2676-2717, 436-443, 2666-2674
+    def init_optimizer(self):
+        c = self.config
+        o = _cfg(c, "training.optim", {})
+        lss = _cfg(c, "training.losses", {})
+        lr = float(o.get("prediction_model_learning_rate", 1e-6))
+        ulr = float(o.get("prediction_model_upper_learning_rate", lr))
+        bs = int(_cfg(c, "data.dataloader.train_batch_size", 8))
+        if o.get("scale_lr", False):
+            s = (int(_cfg(c, "training.gradient_accumulation_steps", 1)) * bs * self.world) ** 0.5
+            lr, ulr = lr * s, ulr * s
+        g = lambda name, key, d: float((lss.get(name) or {}).get(key, d) or 0.0)
+        self.stepper = BilevelStepper(
+            self.prediction_model, self.teacher_model,
+            w_diff=g("diffusion_loss", "weight", 1.0), w_dist=g("distillation_loss", "weight", 0.0),
+            w_block=g("block_loss", "weight", 0.0), snr_gamma=(lss.get("diffusion_loss") or {}).get("snr_gamma", 5.0),
+            up_w_dist=g("distillation_loss", "upper_weight", 1.0), up_w_block=g("block_loss", "upper_weight", 0.0),
+            prediction_type=_cfg(c, "model.prediction_model.prediction_type", "v_prediction"),
+            lr=lr, upper_lr=ulr, betas=(float(o.get("adam_beta1", 0.9)), float(o.get("adam_beta2", 0.999))),
+            eps=float(o.get("adam_epsilon", 1e-8)), weight_decay=float(o.get("prediction_model_weight_decay", 0.0)),
+            warmup_steps=int(o.get("lr_warmup_steps", 0)),
+            upper_warmup_steps=int(o.get("upper_lr_warmup_steps", o.get("lr_warmup_steps", 0))), bilevel=self.bilevel)
+        self.max_grad_norm = float(o["max_grad_norm"]) if o.get("clip_grad_norm") else None
+
+    def init_dataloader(self, upper):
+        c = self.config
+        if not _cfg(c, "synthetic", False):
+            raise NotImplementedError(
+                "image datasets + VAE/CLIP encoding are SURVEY 8f rows N1/N2 (not built yet): pass a dataloader "
+                "yielding {'latents','prompt_embeds','empty_prompt_embeds'} or run with --synthetic")
+        bs = int(_cfg(c, "data.dataloader.train_batch_size", 8))
+        res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
+        seed = int(_cfg(c, "seed", 43)) + self.rank + (7919 if upper else 0)
+        T = 13 if _cfg(c, "tiny", False) else 77
+        return SyntheticBatches(bs, res, T, self.unet_config.cross_attention_dim, seed, self.device)
+
+    # ---- sampling prologue shared by step/upper_step (trainer.py:2405-2423)
+    def _sample(self, batch):
+        if "latents" not in batch:
+            raise NotImplementedError("batch has no 'latents': VAE encode of pixel_values is SURVEY 8f row N1")
+        lat = batch["latents"].to(self.device, torch.float32)
+        noise = torch.randn(lat.shape, device=self.device, generator=self.rng)
+        off = float(_cfg(self.config, "model.prediction_model.noise_offset", 0.0) or 0.0)
+        if off:
+            noise = noise + off * torch.randn((lat.shape[0], lat.shape[1], 1, 1), device=self.device, generator=self.rng)
+        mx = int(_cfg(self.config, "model.prediction_model.max_scheduler_steps", 1000) or 1000)
+        t = torch.randint(0, mx, (lat.shape[0],), device=self.device, generator=self.rng).long()
+        return lat, noise, t
+
+    def step(self, batch):
+        lat, noise, t = self._sample(batch)
+        L = self.stepper.main_step(lat, noise, t, batch["prompt_embeds"])
+        return self._tuple(L, upper=False)
+
+    def _tuple(self, L, upper):
+        w = self.stepper.w
+        d, s, b = L[0], L[1], L[2]
+        tot = (w["up_dist"] * s + w["up_block"] * b) if upper else (w["diff"] * d + w["block"] * b + w["dist"] * s)
+        return tot.float(), (torch.zeros_like(d) if upper else d).float(), s.float(), b.float()
+
+    # ---- checkpointing (trainer.py:452-514, 2863-2869)
+    def save_checkpoint(self):
+        if self.rank != 0:
+            return
+        d = os.path.join(self.logging_dir, f"checkpoint-{self.global_step}")
+        self.prediction_model.save_pretrained(os.path.join(d, "unet"))
+        torch.save(self.arch_vector, os.path.join(d, "arch_vector.pt"))
+        torch.save(self.stepper.opt.state_dict(), os.path.join(d, "optimizer.bin"))
+        if self.stepper.upper_opt is not None:
+            torch.save(self.stepper.upper_opt.state_dict(), os.path.join(d, "optimizer_1.bin"))
+        with open(os.path.join(d, f"random_states_{self.rank}.pkl"), "wb") as f:
+            pickle.dump({"torch_cuda": self.rng.get_state().cpu()}, f)
+        limit = _cfg(self.config, "training.logging.checkpoints_total_limit")
+        if limit:
+            cks = sorted(glob.glob(os.path.join(self.logging_dir, "checkpoint-*")), key=lambda p: int(p.split("-")[-1]))
+            for old in cks[:-int(limit)]:
+                import shutil
+                shutil.rmtree(old, ignore_errors=True)
+        logger.info("Saved state to %s", d)
+
+    def load_checkpoint(self):
+        r = _cfg(self.config, "training.logging.resume_from_checkpoint")
+        if not r:
+            return
+        if r == "latest":
+            cks = sorted(glob.glob(os.path.join(self.logging_dir, "checkpoint-*")), key=lambda p: int(p.split("-")[-1]))
+            r = cks[-1] if cks else None
+        if not r or not os.path.isdir(r):
+            logger.info("Checkpoint %r does not exist. Starting a new training run.", r)
+            return
+        self.prediction_model.load_pretrained_dir(os.path.join(r, "unet"))
+        self.stepper.opt.load_state_dict(torch.load(os.path.join(r, "optimizer.bin")))
+        if self.stepper.upper_opt is not None and os.path.exists(os.path.join(r, "optimizer_1.bin")):
+            self.stepper.upper_opt.load_state_dict(torch.load(os.path.join(r, "optimizer_1.bin")))
+        self.global_step = int(os.path.basename(r.rstrip("/")).split("-")[1])        # trainer.py:506
+        logger.info("Resumed from %s at global step %d", r, self.global_step)
+
+    def _log(self, rec):
+        if self.rank == 0:
+            os.makedirs(self.logging_dir, exist_ok=True)
+            with open(os.path.join(self.logging_dir, "metrics.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+
+
+class UnetFineTuner(Trainer):
+    """Single-level fine-tune (trainer.py:2116-2574)."""
+
+    def train(self):
+        c = self.config
+        max_steps = int(_cfg(c, "training.max_train_steps", 100))
+        ck_every = int(_cfg(c, "training.logging.checkpoint_steps", _cfg(c, "training.checkpoint_steps", 10000)))
+        freq = int(_cfg(c, "training.upper_step_freq", 10))
+        self.load_checkpoint()
+        upper_iter = iter(self.upper_dataloader) if self.bilevel else None
+        pending = None
+        t0 = time.time()
+        for batch in self.train_dataloader:
+            if self.global_step >= max_steps:
+                break
+            if batch["prompt_embeds"].numel() == 0:          # empty batch is skipped (trainer.py:2771-2772)
+                continue
+            loss = self.step(batch)
+            lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
+            rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
+            keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
+            vals = [torch.stack(loss)]
+            if self.bilevel and (self.global_step + 1) % freq == 0:          # trainer.py:2795-2816
+                try:
+                    ub = next(upper_iter)
+                except StopIteration:
+                    upper_iter = iter(self.upper_dataloader)
+                    ub = next(upper_iter)
+                up = self.upper_step(ub)
+                rec["finetuning/upper_prediction_model_lr"] = self.stepper.optimizer_step(upper=True,
+                                                                                          max_grad_norm=self.max_grad_norm)
+                keys += ("finetuning/upper_loss", "finetuning/upper_diffusion_loss",
+                         "finetuning/upper_distillation_loss", "finetuning/upper_block_loss")
+                vals.append(torch.stack(up))
+            host = torch.cat(vals).to("cpu", non_blocking=True)       # read back asynchronously, log one step late
+            if pending is not None:
+                self._flush(*pending)
+            pending = (rec, keys, host, torch.cuda.Event())
+            pending[3].record()
+            self.global_step += 1
+            if self.global_step % ck_every == 0:
+                self.save_checkpoint()
+        if pending is not None:
+            self._flush(*pending)
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        self.save_checkpoint()
+        logger.info("finished %d steps in %.1fs", self.global_step, time.time() - t0)
+
+    def _flush(self, rec, keys, host, ev):
+        ev.synchronize()
+        rec.update({k_: float(v) for k_, v in zip(keys, host.tolist())})
+        self._log(rec)
+
+
+class BilevelUnetFineTuner(UnetFineTuner):
+    """Bilevel fine-tune + concept suppression (trainer.py:2577-3001)."""
+    bilevel = True
+
+    def upper_step(self, batch):
+        lat, noise, t = self._sample(batch)
+        L = self.stepper.upper_step(lat, noise, t, batch["prompt_embeds"], batch["empty_prompt_embeds"])
+        return self._tuple(L, upper=True)
+
+
+class NudityBilevelUnetFineTuner(BilevelUnetFineTuner):
+    """Same as BilevelUnetFineTuner; only the upper dataset selection differs (trainer.py:3004-3016)."""
