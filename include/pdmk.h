@@ -130,8 +130,10 @@ int pdmk_copy2d(const void* src, void* dst, int64_t rows, int cols, int lds, int
  * mode 0: dst[i] = src[i];   mode 1 (n1==1): [n0,n2] -> [n2,n0]   (Linear W^T for dgrad);
  * mode 2: conv [n0=Co, n1=9, n2=Ci] -> [Ci, 9 (taps flipped: t -> 8-t), Co]   (conv dgrad weights). */
 int pdmk_cast_permute(const float* src, void* dst, int n0, int n1, int n2, int mode, int dtype, pdmk_stream stream);
-/* column sums: out[n] (+)= sum_m x[m*ld + n]  (bias gradients). out fp32. */
-int pdmk_colsum(const void* x, float* out, int64_t M, int N, int ld, int accumulate, int dtype, pdmk_stream stream);
+/* column sums per batch: out[b*N + n] (+)= sum_{r<rows} x[(b*rows + r)*ld + n], b < nbatch  (bias gradients with
+ * nbatch=1; gradient of the broadcast time-embedding add, blocks.py:334-341, with nbatch=B). out fp32. */
+int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch, int dtype,
+                pdmk_stream stream);
 /* backward of nearest x2 upsample: dst[b,y,x,c] = sum of the 2x2 block of src [B,2H,2W,C]. */
 int pdmk_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, int dtype, pdmk_stream stream);
 /* Timesteps(dim, flip_sin_to_cos=True, shift 0) (unet_2d_conditional.py:1514-1519): out[b] = [cos(t f_i), sin(t f_i)],

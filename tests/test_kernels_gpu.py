@@ -309,7 +309,8 @@ def test_scalar_kernels(dev):
     out = torch.zeros(len(t), 320, device=dev)
     freqs = torch.exp(-math.log(10000.0) * torch.arange(160, dtype=torch.float32) / 160).to(dev)
     k.timestep_embed(t, freqs, out, len(t), 320)
-    close(out, torch.from_numpy(gold["temb_ref"]).to(dev), 2e-5, "timestep_embed vs ldm twin")
+    # tolerance: sin/cos of a fp32 argument up to 999 rad is conditioned at |x| * 2^-24 = 6e-5 (one ulp of the argument)
+    close(out, torch.from_numpy(gold["temb_ref"]).to(dev), 1e-4, "timestep_embed vs ldm twin")
     # forward diffusion
     Bn, Cc, HW = 3, 4, 64
     x0, nz = torch.randn(Bn, Cc, HW, device=dev), torch.randn(Bn, Cc, HW, device=dev)

@@ -168,35 +168,56 @@ template <typename T> int cast_permute(const float* src, void* dst, int n0, int 
 }
 
 // ------------------------------------------------------------------------------------------------ colsum
+// out[batch][n] (+)= sum over the rows of that batch of x[row][n].  Rows are read fully coalesced: a 256-thread block
+// is (rows-in-flight x column chunks); partial sums are combined across the rows-in-flight in LDS, then ONE float
+// atomic per column per block (blocks per batch are capped so same-address atomic contention stays low).
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, int ld,
-                              long rows_per_blk) {
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int N,
+                                                    int ld, long rows_per_blk, int tpr) {
     constexpr int V = Vec<T>::N;
+    __shared__ float red[NT * V];
     const int nc = N / V;
-    const long r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
-    for (int c = blockIdx.x * NT + threadIdx.x; c < nc; c += gridDim.x * NT) {
-        float s[V];
+    const int tid = threadIdx.x, ct = tid % tpr, ro = tid / tpr, rif = NT / tpr;
+    const int c = blockIdx.x * tpr + ct;
+    const long base = (long)blockIdx.z * rows;
+    const long r0 = blockIdx.y * rows_per_blk, r1 = min(rows, r0 + rows_per_blk);
+    float s[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) s[e] = 0.f;
-        for (long r = r0; r < r1; ++r) {
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (c < nc) {
+        for (long r = r0 + ro; r < r1; r += rif) {
             float f[V];
-            Vec<T>::load(x + r * ld + c * V, f);
+            Vec<T>::load(x + (base + r) * ld + c * V, f);
 #pragma unroll
             for (int e = 0; e < V; ++e) s[e] += f[e];
         }
+    }
 #pragma unroll
-        for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[c * V + e], s[e]);
+    for (int e = 0; e < V; ++e) red[tid * V + e] = s[e];
+    __syncthreads();
+    if (ro == 0 && c < nc) {
+        for (int j = 1; j < rif; ++j)
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += red[(j * tpr + ct) * V + e];
+#pragma unroll
+        for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[(long)blockIdx.z * N + c * V + e], s[e]);
     }
 }
-template <typename T> int colsum(const void* x, float* out, long M, int N, int ld, int acc, hipStream_t st) {
+template <typename T>
+int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nbatch, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (N % V || ld % V) return -1;
-    if (!acc && hipMemsetAsync(out, 0, sizeof(float) * N, st) != hipSuccess) return -1000;
-    const int gx = (N / V + NT - 1) / NT;
-    const int gy = (int)max(1L, min(M, 2048L / gx));
-    const long rpb = (M + gy - 1) / gy;
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (int)((M + rpb - 1) / rpb)), dim3(NT), 0, st, (const T*)x, out, M, N,
-                       ld, rpb);
+    if (!acc && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * nbatch, st) != hipSuccess) return -1000;
+    const int nc = N / V;
+    int tpr = 1;
+    while (tpr < nc && tpr < NT) tpr <<= 1;
+    const int rif = NT / tpr;
+    const int gx = (nc + tpr - 1) / tpr;
+    long gy = max(1L, min(rows / max(1, rif * 4), (long)max(1, 512 / (gx * nbatch))));
+    const long rpb = (rows + gy - 1) / gy;
+    gy = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (int)gy, nbatch), dim3(NT), 0, st, (const T*)x, out, rows, N, ld, rpb,
+                       tpr);
     PDMK_CHECK_LAUNCH();
     return 0;
 }
@@ -418,10 +439,10 @@ extern "C" int pdmk_cast_permute(const float* src, void* dst, int n0, int n1, in
     if (mode == 1 && n1 != 1) return -1;
     PDMK_DISPATCH(dtype, cast_permute, src, dst, n0, n1, n2, mode, (hipStream_t)s);
 }
-extern "C" int pdmk_colsum(const void* x, float* out, int64_t M, int N, int ld, int accumulate, int dtype,
-                           pdmk_stream s) {
-    if (!x || !out || M <= 0 || N <= 0) return -1;
-    PDMK_DISPATCH(dtype, colsum, x, out, (long)M, N, ld, accumulate, (hipStream_t)s);
+extern "C" int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch,
+                           int dtype, pdmk_stream s) {
+    if (!x || !out || rows <= 0 || N <= 0 || nbatch <= 0) return -1;
+    PDMK_DISPATCH(dtype, colsum, x, out, (long)rows, N, ld, accumulate, nbatch, (hipStream_t)s);
 }
 extern "C" int pdmk_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, int dtype, pdmk_stream s) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;

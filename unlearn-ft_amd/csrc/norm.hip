@@ -195,12 +195,23 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ 
         }
     }
     __shared__ float ls[2][64];
+    __shared__ float red[2][NT * V];
     if (tid < 128) ls[tid >> 6][tid & 63] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int sl = 0; sl < MAXS; ++sl) {
         const int c = cb + mp.tpr * sl;
-        if (c < nchunks) {
+        // combine the rows-in-flight of this block in LDS: one global atomic per channel per block
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < V; ++e) { red[0][tid * V + e] = a1[sl][e]; red[1][tid * V + e] = a2[sl][e]; }
+        __syncthreads();
+        if (ro == 0 && c < nchunks) {
+            for (int j = 1; j < mp.rif; ++j)
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    a1[sl][e] += red[0][(j * mp.tpr + cb) * V + e];
+                    a2[sl][e] += red[1][(j * mp.tpr + cb) * V + e];
+                }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 const int ch = c * V + e;
@@ -282,9 +293,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
     }
 }
 
-inline int gn_rows_per_blk(int B, int HW, int rif) {
-    // aim for ~1024 blocks chip-wide, at least one sweep of rows-in-flight per block
-    int nchunk = max(1, min(HW / max(1, rif), (1024 + B - 1) / B));
+inline int gn_rows_per_blk(int B, int HW, int rif, int target_blocks = 1024) {
+    // aim for ~target_blocks blocks chip-wide, at least one sweep of rows-in-flight per block
+    int nchunk = max(1, min(HW / max(1, rif), (target_blocks + B - 1) / B));
     return (HW + nchunk - 1) / nchunk;
 }
 
@@ -311,11 +322,14 @@ int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || lddy % V || lddx % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
     const GnMap mp = gn_map(C / V);
+    // the stats pass ends in per-channel float atomics on shared addresses: fewer, fatter blocks (about one per CU)
+    const int rpb_s = gn_rows_per_blk(B, HW, mp.rif, 256);
+    dim3 grid_s((HW + rpb_s - 1) / rpb_s, B);
     const int rpb = gn_rows_per_blk(B, HW, mp.rif);
     dim3 grid((HW + rpb - 1) / rpb, B);
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) return -1000;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
-                       dgamma, dbeta, ws, HW, C, ldx, lddy, G, gs, silu, rpb);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, grid_s, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
+                       dgamma, dbeta, ws, HW, C, ldx, lddy, G, gs, silu, rpb_s);
     hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, (T*)dx, gamma, beta,
                        stats, ws, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb);
     PDMK_CHECK_LAUNCH();
@@ -324,7 +338,6 @@ int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 constexpr int LN_MAXS = 5;   // per-lane chunk slots: C <= 5*64*chunk
-constexpr int LN_ROWS_BWD = 8;
 
 template <typename T>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
                                                     T* __restrict__ dx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, int M, int C, int ldx, int lddy,
-                                                    int lddx, int accumulate) {
+                                                    int lddx, int accumulate, int rows_per_wave) {
     constexpr int V = Vec<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = C / V;
@@ -390,8 +403,8 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
             gm[sl][e] = (c < nchunks) ? gamma[c * V + e] : 0.f;
         }
     }
-    const int mbase = (blockIdx.x * 4 + wave) * LN_ROWS_BWD;
-    for (int rr = 0; rr < LN_ROWS_BWD; ++rr) {
+    const int mbase = (blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int m = mbase + rr;
         if (m >= M) break;
         const float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
@@ -431,14 +444,24 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
             }
         }
     }
+    // combine the 4 waves in LDS, then one atomic per channel per block
+    __shared__ float red[2][3][64 * V];
 #pragma unroll
     for (int sl = 0; sl < LN_MAXS; ++sl) {
         const int c = lane + 64 * sl;
-        if (c < nchunks) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) { red[0][wave - 1][lane * V + e] = ag[sl][e]; red[1][wave - 1][lane * V + e] = ab[sl][e]; }
+        }
+        __syncthreads();
+        if (wave == 0 && c < nchunks) {
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                unsafeAtomicAdd(&dgamma[c * V + e], ag[sl][e]);
-                unsafeAtomicAdd(&dbeta[c * V + e], ab[sl][e]);
+                const float g2 = ag[sl][e] + red[0][0][lane * V + e] + red[0][1][lane * V + e] + red[0][2][lane * V + e];
+                const float b2 = ab[sl][e] + red[1][0][lane * V + e] + red[1][1][lane * V + e] + red[1][2][lane * V + e];
+                unsafeAtomicAdd(&dgamma[c * V + e], g2);
+                unsafeAtomicAdd(&dbeta[c * V + e], b2);
             }
         }
     }
@@ -459,9 +482,12 @@ int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
            float* dbeta, int M, int C, int ldx, int lddy, int lddx, int acc, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64) return -1;
-    const int rows_per_blk = 4 * LN_ROWS_BWD;
+    // about 512 blocks: enough to stream at HBM rate, few enough that the per-channel atomics do not contend
+    int rpw = (M + 512 * 4 - 1) / (512 * 4);
+    rpw = rpw < 1 ? 1 : (rpw > 64 ? 64 : rpw);
+    const int rows_per_blk = 4 * rpw;
     hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((M + rows_per_blk - 1) / rows_per_blk), dim3(NT), 0, st, (const T*)x,
-                       (const T*)dy, (T*)dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, acc);
+                       (const T*)dy, (T*)dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, acc, rpw);
     PDMK_CHECK_LAUNCH();
     return 0;
 }

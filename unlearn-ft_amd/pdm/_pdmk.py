@@ -58,7 +58,7 @@ _SIGS = {
     "pdmk_silu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
     "pdmk_copy2d": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_cast_permute": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    "pdmk_colsum": ([vp, vp, i64, i32, i32, i32, i32, vp], i32),
+    "pdmk_colsum": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_pool2x2_sum": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_timestep_embed": ([vp, vp, vp, i32, i32, i32, vp], i32),
     "pdmk_add_noise_velocity": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
@@ -188,8 +188,8 @@ def cast_permute(src, dst, n0, n1, n2, mode):
     _chk(_lib.pdmk_cast_permute(_p(src), _p(dst), n0, n1, n2, mode, dt(dst), _st()), "pdmk_cast_permute")
 
 
-def colsum(x, out, M, N, ld, accumulate=False):
-    _chk(_lib.pdmk_colsum(_p(x), _p(out), M, N, ld, int(accumulate), dt(x), _st()), "pdmk_colsum")
+def colsum(x, out, rows, N, ld, accumulate=False, nbatch=1):
+    _chk(_lib.pdmk_colsum(_p(x), _p(out), rows, N, ld, int(accumulate), nbatch, dt(x), _st()), "pdmk_colsum")
 
 
 def pool2x2_sum(src, dst, B, H, W, Cc):

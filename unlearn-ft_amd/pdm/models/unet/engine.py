@@ -93,7 +93,7 @@ class UNetEngine:
                 if x.rg:
                     dx, acc = self._grad_into(x, M, Kp)
                     k.gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc, macs=lmacs)
-                sk = self._splitk(Np, Kp, M, 32)
+                sk = self._splitk(Np, Kp, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
                        b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
                 if bias:
@@ -138,7 +138,7 @@ class UNetEngine:
                         k.gemm(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
                                a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
                                accumulate=acc, macs=lmacs)
-                sk = self._splitk(Cop, 9 * Cip, M, 32)
+                sk = self._splitk(Cop, 9 * Cip, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
                        b_mode=k.B_COLK_CONV, conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), out_f32=True, splitk=sk,
                        accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
@@ -146,8 +146,7 @@ class UNetEngine:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
                     dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
                     hw = Ho * Wo
-                    for b in range(B):
-                        k.colsum(dy[b * hw:(b + 1) * hw], dtp[b], hw, Cop, ldy)
+                    k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B)
                     k.colsum(dtp, P.g(bias), B, Cop, Cop, accumulate=True)
                     rowvec.g = dtp
                 else:
