@@ -167,6 +167,10 @@ def main():
         torch.cuda.synchronize()
         prof, k.PROFILE = k.PROFILE, None
         agg = {}
+        if os.environ.get("PDMK_DUMP_GEMM"):
+            with open(os.environ["PDMK_DUMP_GEMM"], "w") as f:
+                for kind, flops, e0, e1, shp in prof:
+                    f.write(json.dumps({"kind": list(kind), "flops": flops, "ms": e0.elapsed_time(e1), "mnk_sk": shp}) + "\n")
         for kind, flops, e0, e1, shp in prof:
             ms = e0.elapsed_time(e1)
             r = agg.setdefault(kind, [0.0, 0.0, 0])

@@ -74,6 +74,11 @@ typedef struct pdmk_gemm_args {
 } pdmk_gemm_args;
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
+/* Second half of a split-K forward/dgrad GEMM (small-M layers at 8x8 / 16x16 latents: too few output tiles to fill 256
+ * CUs): pdmk_gemm accumulated fp32 partials into the zeroed workspace ws[M,N] (out_f32, splitk>1); this applies the
+ * epilogue C = (accumulate ? C : 0) + ws + bias + rowvec + R and stores in `dtype`. */
+int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
+                       int N, int ldc, int ldr, int rows_per_b, int accumulate, int dtype, pdmk_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC.  Replaces F.group_norm + F.silu at blocks.py:318-319, 348+371,

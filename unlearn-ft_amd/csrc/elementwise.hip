@@ -185,7 +185,17 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, flo
 #pragma unroll
     for (int e = 0; e < V; ++e) s[e] = 0.f;
     if (c < nc) {
-        for (long r = r0 + ro; r < r1; r += rif) {
+        long r = r0 + ro;
+        for (; r + 3L * rif < r1; r += 4L * rif) {     // 4 independent 16-byte loads in flight per lane
+            float f0[V], f1[V], f2[V], f3[V];
+            Vec<T>::load(x + (base + r) * ld + c * V, f0);
+            Vec<T>::load(x + (base + r + rif) * ld + c * V, f1);
+            Vec<T>::load(x + (base + r + 2L * rif) * ld + c * V, f2);
+            Vec<T>::load(x + (base + r + 3L * rif) * ld + c * V, f3);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += (f0[e] + f1[e]) + (f2[e] + f3[e]);
+        }
+        for (; r < r1; r += rif) {
             float f[V];
             Vec<T>::load(x + (base + r) * ld + c * V, f);
 #pragma unroll
@@ -213,7 +223,7 @@ int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nba
     while (tpr < nc && tpr < NT) tpr <<= 1;
     const int rif = NT / tpr;
     const int gx = (nc + tpr - 1) / tpr;
-    long gy = max(1L, min(rows / max(1, rif * 4), (long)max(1, 512 / (gx * nbatch))));
+    long gy = max(1L, min(rows / max(1, rif * 8), (long)max(1, 1024 / (gx * nbatch))));
     const long rpb = (rows + gy - 1) / gy;
     gy = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (int)gy, nbatch), dim3(NT), 0, st, (const T*)x, out, rows, N, ld, rpb,
@@ -361,6 +371,38 @@ __global__ void mse_bwd_kernel(const void* __restrict__ a, int adt, const void* 
             float* p = reinterpret_cast<float*>(da);
             p[o] = g + (acc ? p[o] : 0.f);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ split-K finish
+// C[m][n] = (acc ? C : 0) + ws[m][n] + bias[n] + rowvec[m / rows_per_b][n] + R[m][n]   (ws: fp32 split-K partial sums)
+template <typename T>
+__global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ C, const float* __restrict__ bias,
+                                     const float* __restrict__ rowvec, const T* __restrict__ R, long M, int N, int ldc,
+                                     int ldr, int rows_per_b, int acc) {
+    const int nc = N / 4;
+    const long total = M * nc;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long m = i / nc;
+        const int n = (int)(i - m * nc) * 4;
+        const float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
+        float v[4] = {w.x, w.y, w.z, w.w};
+        if (bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
+        }
+        if (rowvec) {
+            const float* rv = rowvec + (m / rows_per_b) * N + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rv[e];
+        }
+        if (R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += to_f32(R[m * ldr + n + e]);
+        }
+        T* c = C + m * ldc + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = from_f32<T>(v[e] + (acc ? to_f32(c[e]) : 0.f));
     }
 }
 
@@ -518,6 +560,21 @@ extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, con
     if (!p || !g || !m || !v || !lr || !bias_corr || n <= 0 || (n & 3)) return -1;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
                        beta1, beta2, eps, weight_decay, bias_corr, grad_scale, zero_grad);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R,
+                                  int64_t M, int N, int ldc, int ldr, int rows_per_b, int accumulate, int dtype,
+                                  pdmk_stream s) {
+    if (!ws || !C || M <= 0 || N <= 0 || (N & 3) || (rowvec && rows_per_b <= 0)) return -1;
+    dim3 grid(grid_for(M * (N / 4)));
+    if (dtype == PDMK_BF16)
+        hipLaunchKernelGGL(splitk_finish_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, ws, (bf16*)C, bias, rowvec,
+                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, accumulate);
+    else if (dtype == PDMK_F32)
+        hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
+                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, accumulate);
+    else return -2;
     PDMK_CHECK_LAUNCH();
     return 0;
 }

@@ -173,16 +173,21 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ 
             }
         }
     }
-    for (int r = r0 + ro; r < r1; r += mp.rif) {
+    for (int r = r0 + ro; r < r1; r += 2 * mp.rif) {      // two rows per iteration: 4 independent loads per slot
+        const bool two = r + mp.rif < r1;
         const T* row = x + ((long)b * HW + r) * ldx;
         const T* drow = dy + ((long)b * HW + r) * lddy;
+        const T* row2 = two ? row + (long)mp.rif * ldx : row;
+        const T* drow2 = two ? drow + (long)mp.rif * lddy : drow;
 #pragma unroll
         for (int sl = 0; sl < MAXS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[V], d[V];
+                float f[V], d[V], f2[V], d2[V];
                 Vec<T>::load(row + c * V, f);
                 Vec<T>::load(drow + c * V, d);
+                Vec<T>::load(row2 + c * V, f2);
+                Vec<T>::load(drow2 + c * V, d2);
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
                     const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
@@ -190,6 +195,11 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ 
                     if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
                     a1[sl][e] += dz;
                     a2[sl][e] += dz * xh;
+                    const float xh2 = (f2[e] - mean[sl][e]) * rstd[sl][e];
+                    float dz2 = two ? d2[e] : 0.f;
+                    if (silu) dz2 *= silu_grad_f(xh2 * gm[sl][e] + bt[sl][e]);
+                    a1[sl][e] += dz2;
+                    a2[sl][e] += dz2 * xh2;
                 }
             }
         }
@@ -384,7 +394,9 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, T* 
     }
 }
 
-template <typename T>
+// backward: each wave walks its rows R at a time (R independent row loads in flight: the row reductions make a single
+// row latency-bound); SLOTS = 16-byte chunks per lane is a template parameter so small C does not pay registers for 1280.
+template <typename T, int SLOTS, int R>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                     T* __restrict__ dx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, float* __restrict__ dgamma,
@@ -393,9 +405,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
     constexpr int V = Vec<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = C / V;
-    float gm[LN_MAXS][V], ag[LN_MAXS][V], ab[LN_MAXS][V];
+    float gm[SLOTS][V], ag[SLOTS][V], ab[SLOTS][V];
 #pragma unroll
-    for (int sl = 0; sl < LN_MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = lane + 64 * sl;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -404,50 +416,69 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
         }
     }
     const int mbase = (blockIdx.x * 4 + wave) * rows_per_wave;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int m = mbase + rr;
-        if (m >= M) break;
-        const float mean = stats[2 * (long)m], rstd = stats[2 * (long)m + 1];
-        float xh[LN_MAXS][V], d[LN_MAXS][V];
-        float s1 = 0.f, s2 = 0.f;
+    const int mend = min(M, mbase + rows_per_wave);
+    const float invC = 1.0f / C;
+    for (int m0 = mbase; m0 < mend; m0 += R) {
+        float xh[R][SLOTS][V], d[R][SLOTS][V], mean[R], rstd[R];
 #pragma unroll
-        for (int sl = 0; sl < LN_MAXS; ++sl) {
-            const int c = lane + 64 * sl;
-            if (c < nchunks) {
-                Vec<T>::load(x + (long)m * ldx + c * V, xh[sl]);
-                Vec<T>::load(dy + (long)m * lddy + c * V, d[sl]);
+        for (int q = 0; q < R; ++q) {
+            const int m = min(m0 + q, mend - 1);          // clamp: duplicates of the last row are discarded below
+            mean[q] = stats[2 * (long)m];
+            rstd[q] = stats[2 * (long)m + 1];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    xh[sl][e] = (xh[sl][e] - mean) * rstd;
-                    ab[sl][e] += d[sl][e];
-                    ag[sl][e] += d[sl][e] * xh[sl][e];
-                    const float g = d[sl][e] * gm[sl][e];
-                    s1 += g;
-                    s2 += g * xh[sl][e];
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = lane + 64 * sl;
+                if (c < nchunks) {
+                    Vec<T>::load(x + (long)m * ldx + c * V, xh[q][sl]);
+                    Vec<T>::load(dy + (long)m * lddy + c * V, d[q][sl]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) xh[q][sl][e] = d[q][sl][e] = 0.f;
                 }
             }
         }
-        s1 = wave_sum(s1) / C;
-        s2 = wave_sum(s2) / C;
 #pragma unroll
-        for (int sl = 0; sl < LN_MAXS; ++sl) {
-            const int c = lane + 64 * sl;
-            if (c < nchunks) {
-                float o[V];
-                if (accumulate) Vec<T>::load(dx + (long)m * lddx + c * V, o);
+        for (int q = 0; q < R; ++q) {
+            const bool live = m0 + q < mend;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = lane + 64 * sl;
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    const float v = rstd * (d[sl][e] * gm[sl][e] - s1 - xh[sl][e] * s2);
-                    o[e] = accumulate ? o[e] + v : v;
+                    const float h = (c < nchunks) ? (xh[q][sl][e] - mean[q]) * rstd[q] : 0.f;
+                    xh[q][sl][e] = h;
+                    if (live) { ab[sl][e] += d[q][sl][e]; ag[sl][e] += d[q][sl][e] * h; }
+                    const float g = d[q][sl][e] * gm[sl][e];
+                    s1 += g;
+                    s2 += g * h;
                 }
-                Vec<T>::store(dx + (long)m * lddx + c * V, o);
+            }
+            s1 = wave_sum(s1) * invC;
+            s2 = wave_sum(s2) * invC;
+            if (live) {
+                const int m = m0 + q;
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int c = lane + 64 * sl;
+                    if (c < nchunks) {
+                        float o[V];
+                        if (accumulate) Vec<T>::load(dx + (long)m * lddx + c * V, o);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float v = rstd[q] * (d[q][sl][e] * gm[sl][e] - s1 - xh[q][sl][e] * s2);
+                            o[e] = accumulate ? o[e] + v : v;
+                        }
+                        Vec<T>::store(dx + (long)m * lddx + c * V, o);
+                    }
+                }
             }
         }
     }
     // combine the 4 waves in LDS, then one atomic per channel per block
     __shared__ float red[2][3][64 * V];
 #pragma unroll
-    for (int sl = 0; sl < LN_MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = lane + 64 * sl;
         __syncthreads();
         if (wave > 0) {
@@ -484,10 +515,17 @@ int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
     if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64) return -1;
     // about 512 blocks: enough to stream at HBM rate, few enough that the per-channel atomics do not contend
     int rpw = (M + 512 * 4 - 1) / (512 * 4);
-    rpw = rpw < 1 ? 1 : (rpw > 64 ? 64 : rpw);
+    rpw = rpw < 4 ? 4 : (rpw > 64 ? 64 : rpw);
     const int rows_per_blk = 4 * rpw;
-    hipLaunchKernelGGL(ln_bwd_kernel<T>, dim3((M + rows_per_blk - 1) / rows_per_blk), dim3(NT), 0, st, (const T*)x,
-                       (const T*)dy, (T*)dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, acc, rpw);
+    const dim3 grid((M + rows_per_blk - 1) / rows_per_blk);
+    const int slots = (C / V + 63) / 64;
+#define PDMK_LNB(S, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, S, RR>), grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, \
+                                           (T*)dx, gamma, stats, dgamma, dbeta, M, C, ldx, lddy, lddx, acc, rpw)
+    if (slots <= 1) PDMK_LNB(1, 4);
+    else if (slots == 2) PDMK_LNB(2, 2);
+    else if (slots == 3) PDMK_LNB(3, 2);
+    else PDMK_LNB(LN_MAXS, 1);
+#undef PDMK_LNB
     PDMK_CHECK_LAUNCH();
     return 0;
 }

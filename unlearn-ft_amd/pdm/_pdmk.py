@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
 _SIGS = {
     "pdmk_version": ([], i32),
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
+    "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
@@ -129,6 +130,28 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     e1.record()
     kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode)
     PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
+
+
+def splitk_plan(M, N, K, kstep=64):
+    """Split factor for a forward/dgrad GEMM whose output grid cannot fill the chip (1 = do not split)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    nk = K // kstep
+    if tiles > 192 or nk < 64 or (N & 3):      # only deep-K, few-tile GEMMs (3x3 convs at 8x8 / 16x16 latents)
+        return 1
+    return max(1, min(nk // 16, -(-512 // tiles), 16))
+
+
+def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
+              a_mode=A_ROWK, conv=None, accumulate=False, macs=None):
+    """Forward / dgrad GEMM with the split-K decision made here: small-M layers go through an fp32 workspace."""
+    sk = splitk_plan(M, N, K, 64 if A.dtype == torch.bfloat16 else 32)
+    if sk == 1:
+        return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
+                    a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs)
+    ws = torch.zeros((M, N), device=A.device, dtype=torch.float32)
+    gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, macs=macs)
+    _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b,
+                                 int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")
 
 
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps, silu):

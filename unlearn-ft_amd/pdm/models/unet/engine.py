@@ -66,7 +66,7 @@ class UNetEngine:
     def _splitk(m_out, n_out, red, step):
         tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
         nk = max(1, red // step)
-        return max(1, min(512 // max(tiles, 1), nk // 8, 64))
+        return max(1, min(512 // max(tiles, 1), nk // 32, 64))   # >= 32 K-steps per split (measured sweet spot)
 
     # ------------------------------------------------------------------ ops
     def linear(self, x, key, bias=None, residual=None, out_f32=False):
@@ -76,9 +76,10 @@ class UNetEngine:
         M = x.t.shape[0]
         assert x.t.shape[1] == Kp, f"{key}: input has {x.t.shape[1]} cols, weight expects {Kp}"
         y = self._empty(M, Np, torch.float32 if out_f32 else None)
-        k.gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np,
-               bias=P.p(bias) if bias else None, R=residual.t if residual else None,
-               ldr=_ld(residual.t) if residual else 0, out_f32=out_f32, macs=M * e.logical[0] * e.logical[1])
+        (k.gemm if out_f32 else k.gemm_auto)(
+            x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None,
+            R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
+            macs=M * e.logical[0] * e.logical[1], **({"out_f32": True} if out_f32 else {}))
         lmacs = M * e.logical[0] * e.logical[1]
         if self.count_macs:
             self.macs += lmacs
@@ -92,7 +93,8 @@ class UNetEngine:
                     dy = dyc
                 if x.rg:
                     dx, acc = self._grad_into(x, M, Kp)
-                    k.gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc, macs=lmacs)
+                    k.gemm_auto(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc,
+                                macs=lmacs)
                 sk = self._splitk(Np, Kp, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
                        b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
@@ -112,7 +114,7 @@ class UNetEngine:
         Ho, Wo = ((Hi + 1) // 2, (Wi + 1) // 2) if mode == 1 else ((2 * Hi, 2 * Wi) if mode == 2 else (Hi, Wi))
         M = B * Ho * Wo
         y = self._empty(M, Cop)
-        k.gemm(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
+        k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
                rowvec=rowvec.t if rowvec is not None else None, rows_per_b=Ho * Wo,
                R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
@@ -128,15 +130,15 @@ class UNetEngine:
                 if x.rg:
                     if mode == 2:
                         tmp = self._empty(M, Cip)
-                        k.gemm(dy, P.wtv(key + ".weight"), tmp, M, Cip, 9 * Cop, 0, 9 * Cop, Cip, a_mode=k.A_CONV,
+                        k.gemm_auto(dy, P.wtv(key + ".weight"), tmp, M, Cip, 9 * Cop, 0, 9 * Cop, Cip, a_mode=k.A_CONV,
                                conv=(B, Ho, Wo, Cop, Ho, Wo, 0, ldy), macs=lmacs)
                         pooled = self._empty(B * Hi * Wi, Cip)
                         k.pool2x2_sum(tmp, pooled, B, Hi, Wi, Cip)
                         self._give(x, pooled)
                     else:
                         dx, acc = self._grad_into(x, B * Hi * Wi, Cip)
-                        k.gemm(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
-                               a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
+                        k.gemm_auto(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
+                                    a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
                                accumulate=acc, macs=lmacs)
                 sk = self._splitk(Cop, 9 * Cip, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
