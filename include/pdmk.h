@@ -61,6 +61,8 @@ typedef struct pdmk_gemm_args {
     const float* bias;    /* [N] or NULL */
     const float* rowvec;  /* [M/rows_per_b, N] fp32 or NULL (time-embedding broadcast add, blocks.py:334-341) */
     const void* R;        /* residual [M,N] in dtype, row stride ldr, or NULL (blocks.py:379) */
+    float* colsum_out;    /* PDMK_A_COLK only (wgrad): colsum_out[m] += sum_k A(m,k), i.e. the bias gradient fused
+                             into the weight-gradient pass; NULL to skip */
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldr;
     int32_t rows_per_b;
@@ -176,7 +178,11 @@ int pdmk_axpby(const void* x, void* y, float alpha, float beta, int64_t n, int d
  */
 int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
                float eps, float weight_decay, const float* bias_corr /* [2]: 1-b1^t, 1-b2^t */, float grad_scale,
-               int zero_grad, pdmk_stream stream);
+               int zero_grad, void* w_bf16 /* optional: refreshed bf16 copy of p, same offsets */, pdmk_stream stream);
+/* Refresh of all dgrad weight copies in ONE launch: `table` = ntiles records of 12 int32
+ * {src_off(lo,hi), dst_off(lo,hi), rows, cols, src_ld, dst_ld, r0, c0, 0, 0}; each record transposes one 64x64 tile:
+ * dst[dst_off + c*dst_ld + r] = src[src_off + r*src_ld + c]. src/dst in `dtype`. */
+int pdmk_transpose_tiles(const void* src, void* dst, const int32_t* table, int ntiles, int dtype, pdmk_stream stream);
 /* sum of squares of n floats into out[slot] (double) — gradient-norm clipping (trainer.py:2323-2325). */
 int pdmk_sumsq(const float* x, int64_t n, double* out, int slot, pdmk_stream stream);
 

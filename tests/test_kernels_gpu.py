@@ -90,8 +90,11 @@ def test_gemm_wgrad_linear(dev, dn, splitk):
     P, No, Ki = 300, 72, 136            # P pixels (reduction), dW [No, Ki]
     dY, X = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
     dW = torch.zeros(No, Ki, device=dev)
-    k.gemm(dY, X, dW, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=splitk)
+    db = torch.ones(No, device=dev)
+    k.gemm(dY, X, dW, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=splitk,
+           colsum_out=db)
     close(dW, dY.float().t() @ X.float(), TOL[dn], "wgrad linear")
+    close(db, 1.0 + dY.float().sum(0), TOL[dn], "fused bias gradient")
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
@@ -115,9 +118,11 @@ def test_gemm_wgrad_conv(dev, dn, mode):
     (gw,) = torch.autograd.grad(y, w, dy.float().permute(0, 3, 1, 2))
     P = Bn * Ho * Ho
     dW = torch.zeros(Co, 9 * Ci, device=dev)
+    db = torch.zeros(Co, device=dev)
     k.gemm(dy, x, dW, Co, 9 * Ci, P, Co, 0, 9 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=2,
-           conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci))
+           conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci), colsum_out=db)
     close(dW, conv_w_pack(gw), TOL[dn], f"wgrad conv mode {mode}")
+    close(db, dy.float().sum(dim=(0, 1, 2)), TOL[dn], "fused conv bias gradient")
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
@@ -355,7 +360,9 @@ def test_scalar_kernels(dev):
         opt.step()
         bc = torch.tensor([1 - 0.9 ** stp, 1 - 0.999 ** stp], device=dev)
         gg = g.clone()
-        k.adamw(p, gg, m, v, n, lr, 0.9, 0.999, 1e-8, 0.01, bc, 1.0, True)
+        wb = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        k.adamw(p, gg, m, v, n, lr, 0.9, 0.999, 1e-8, 0.01, bc, 1.0, True, w_bf16=wb)
+        assert torch.equal(wb, p.bfloat16())
         assert (gg == 0).all()
     close(p, pt.detach(), 1e-6, "adamw")
     ss = torch.zeros(2, device=dev, dtype=torch.float64)

@@ -167,6 +167,32 @@ template <typename T> int cast_permute(const float* src, void* dst, int n0, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ batched transpose
+// One launch refreshes every dgrad weight copy: a table of 64x64 tiles, each a strided 2-D transpose
+//   dst[dst_off + c*dst_ld + r] = src[src_off + r*src_ld + c],  r in [r0, r0+64) < rows, c in [c0, c0+64) < cols
+// (Linear W^T; conv [Co][9][Ci] -> [Ci][9 flipped][Co] is nine such transposes).  Both sides coalesced through LDS.
+struct TrTile { int src_off_lo, src_off_hi, dst_off_lo, dst_off_hi, rows, cols, src_ld, dst_ld, r0, c0, pad0, pad1; };
+template <typename T>
+__global__ __launch_bounds__(NT) void transpose_tiles_kernel(const T* __restrict__ src, T* __restrict__ dst,
+                                                             const TrTile* __restrict__ tab) {
+    __shared__ T tile[64][64 + 2];
+    const TrTile t = tab[blockIdx.x];
+    const long so = ((long)t.src_off_hi << 32) | (unsigned)t.src_off_lo;
+    const long dof = ((long)t.dst_off_hi << 32) | (unsigned)t.dst_off_lo;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = t.r0 + ty + 4 * j, c = t.c0 + tx;
+        if (r < t.rows && c < t.cols) tile[ty + 4 * j][tx] = src[so + (long)r * t.src_ld + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int c = t.c0 + ty + 4 * j, r = t.r0 + tx;
+        if (r < t.rows && c < t.cols) dst[dof + (long)c * t.dst_ld + r] = tile[tx][ty + 4 * j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ colsum
 // out[batch][n] (+)= sum over the rows of that batch of x[row][n].  Rows are read fully coalesced: a 256-thread block
 // is (rows-in-flight x column chunks); partial sums are combined across the rows-in-flight in LDS, then ONE float
@@ -409,7 +435,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
 // ------------------------------------------------------------------------------------------------ AdamW / sumsq
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, const float* __restrict__ lrp, float b1, float b2, float eps, float wd,
-                             const float* __restrict__ bc, float gscale, int zero_grad) {
+                             const float* __restrict__ bc, float gscale, int zero_grad, bf16* __restrict__ wout) {
     const float lr = lrp[0], bc1 = bc[0], bc2s = sqrtf(bc[1]);
     const long nv = n / 4;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < nv; i += (long)gridDim.x * NT) {
@@ -426,6 +452,12 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
             pp[e] -= (lr / bc1) * (mm[e] / denom);
         }
         reinterpret_cast<float4*>(p)[i] = P;
+        if (wout) {      // refreshed bf16 compute copy in the same pass (saves re-reading the master arena)
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)pp[e];
+            reinterpret_cast<bf16x4*>(wout)[i] = o;
+        }
         reinterpret_cast<float4*>(m)[i] = Mv;
         reinterpret_cast<float4*>(v)[i] = Vv;
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -480,6 +512,19 @@ extern "C" int pdmk_cast_permute(const float* src, void* dst, int n0, int n1, in
     if (!src || !dst || n0 <= 0 || n1 <= 0 || n2 <= 0 || mode < 0 || mode > 2) return -1;
     if (mode == 1 && n1 != 1) return -1;
     PDMK_DISPATCH(dtype, cast_permute, src, dst, n0, n1, n2, mode, (hipStream_t)s);
+}
+extern "C" int pdmk_transpose_tiles(const void* src, void* dst, const int32_t* table, int ntiles, int dtype,
+                                    pdmk_stream s) {
+    if (!src || !dst || !table || ntiles <= 0) return -1;
+    if (dtype == PDMK_BF16)
+        hipLaunchKernelGGL(transpose_tiles_kernel<bf16>, dim3(ntiles), dim3(NT), 0, (hipStream_t)s, (const bf16*)src,
+                           (bf16*)dst, (const TrTile*)table);
+    else if (dtype == PDMK_F32)
+        hipLaunchKernelGGL(transpose_tiles_kernel<float>, dim3(ntiles), dim3(NT), 0, (hipStream_t)s, (const float*)src,
+                           (float*)dst, (const TrTile*)table);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch,
                            int dtype, pdmk_stream s) {
@@ -556,10 +601,10 @@ extern "C" int pdmk_mse_bwd(const void* a, int a_dtype, const void* b, int b_dty
 }
 extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* lr, float beta1, float beta2,
                           float eps, float weight_decay, const float* bias_corr, float grad_scale, int zero_grad,
-                          pdmk_stream s) {
+                          void* w_bf16, pdmk_stream s) {
     if (!p || !g || !m || !v || !lr || !bias_corr || n <= 0 || (n & 3)) return -1;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
-                       beta1, beta2, eps, weight_decay, bias_corr, grad_scale, zero_grad);
+                       beta1, beta2, eps, weight_decay, bias_corr, grad_scale, zero_grad, (bf16*)w_bf16);
     PDMK_CHECK_LAUNCH();
     return 0;
 }

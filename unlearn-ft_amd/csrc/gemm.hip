@@ -123,6 +123,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
     uint4 ra[4], rb[4];
     unsigned pmask = 0;   // bit s: ra[s] valid, bit 4+s: rb[s] valid
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    // fused bias gradient (wgrad only): the blocks of the first n-tile also sum their A = dY tiles over the reduction
+    // dim; every tile passes through store_tiles exactly once, which is where the (zero-filled) registers are summed.
+    const bool do_colsum = (AMODE == PDMK_A_COLK) && g.colsum_out != nullptr && n0 == 0;
+    float csum[CH];
+#pragma unroll
+    for (int e = 0; e < CH; ++e) csum[e] = 0.f;
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
@@ -214,6 +220,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 *reinterpret_cast<uint4*>(As + (ckr + TC::KROW_STEP * s) * TC::RS_COLK + cmc) = ra[s];
+            if (do_colsum) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const T* v = reinterpret_cast<const T*>(&ra[s]);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) csum[e] += to_f32(v[e]);
+                }
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(As + (lr + 32 * s) * TC::RS_ROWK + kc) = ra[s];
@@ -262,6 +276,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         if (more) store_tiles(cur ^ 1);
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (do_colsum) {      // combine the KROW_STEP k-row groups through LDS (all tile reads are behind the last barrier)
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < CH; ++e) red[ckr * 128 + cmc + e] = csum[e];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < g.M) {
+            float s = 0.f;
+            for (int j = 0; j < TC::KROW_STEP; ++j) s += red[j * 128 + tid];
+            unsafeAtomicAdd(g.colsum_out + m0 + tid, s);
+        }
     }
 
     // ---------------------------------------------------------------- epilogue

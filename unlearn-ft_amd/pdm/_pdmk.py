@@ -33,7 +33,7 @@ vp, i32, i64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
 
 
 class GemmArgs(C.Structure):
-    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("rowvec", vp), ("R", vp),
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("rowvec", vp), ("R", vp), ("colsum_out", vp),
                 ("M", i32), ("N", i32), ("K", i32),
                 ("lda", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
                 ("rows_per_b", i32), ("a_mode", i32), ("b_mode", i32),
@@ -68,7 +68,8 @@ _SIGS = {
     "pdmk_mse_fwd": ([vp, i32, vp, i32, vp, vp, i32, i32, i64, i32, i32, i32, f64, vp], i32),
     "pdmk_mse_bwd": ([vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, i32, i32, f32, i32, vp], i32),
     "pdmk_axpby": ([vp, vp, f32, f32, i64, i32, vp], i32),
-    "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp], i32),
+    "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp, vp], i32),
+    "pdmk_transpose_tiles": ([vp, vp, vp, i32, i32, vp], i32),
     "pdmk_sumsq": ([vp, i64, vp, i32, vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
@@ -108,9 +109,10 @@ PROFILE = None   # bench.py sets this to a list: every gemm launch is then brack
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
-         macs=None):
+         macs=None, colsum_out=None):
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
+    g.colsum_out = _p(colsum_out)
     g.A, g.B, g.C = _p(A), _p(B), _p(Cout)
     g.bias, g.rowvec, g.R = _p(bias), _p(rowvec), _p(R)
     g.M, g.N, g.K = M, N, K
@@ -250,9 +252,13 @@ def axpby(x, y, alpha, beta):
     _chk(_lib.pdmk_axpby(_p(x), _p(y), float(alpha), float(beta), x.numel(), dt(x), _st()), "pdmk_axpby")
 
 
-def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bias_corr, grad_scale, zero_grad):
+def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bias_corr, grad_scale, zero_grad, w_bf16=None):
     _chk(_lib.pdmk_adamw(_p(p), _p(g), _p(m), _p(v), n, _p(lr), b1, b2, eps, wd, _p(bias_corr), grad_scale,
-                         int(zero_grad), _st()), "pdmk_adamw")
+                         int(zero_grad), _p(w_bf16), _st()), "pdmk_adamw")
+
+
+def transpose_tiles(src, dst, table, ntiles):
+    _chk(_lib.pdmk_transpose_tiles(_p(src), _p(dst), _p(table), ntiles, dt(src), _st()), "pdmk_transpose_tiles")
 
 
 def sumsq(x, n, out, slot):

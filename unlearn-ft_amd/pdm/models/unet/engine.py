@@ -97,9 +97,8 @@ class UNetEngine:
                                 macs=lmacs)
                 sk = self._splitk(Np, Kp, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
-                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
-                if bias:
-                    k.colsum(dy, P.g(bias), M, Np, _ld(dy), accumulate=True)
+                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs,
+                       colsum_out=P.g(bias) if bias else None)        # bias gradient fused into the wgrad pass
                 if residual is not None:
                     self._give(residual, out.g)
             self.tape.append(bwd)
@@ -143,7 +142,8 @@ class UNetEngine:
                 sk = self._splitk(Cop, 9 * Cip, M, 64)
                 k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
                        b_mode=k.B_COLK_CONV, conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), out_f32=True, splitk=sk,
-                       accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs)
+                       accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs,
+                       colsum_out=None if rowvec is not None else P.g(bias))
                 if rowvec is not None:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
                     dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
@@ -151,8 +151,6 @@ class UNetEngine:
                     k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B)
                     k.colsum(dtp, P.g(bias), B, Cop, Cop, accumulate=True)
                     rowvec.g = dtp
-                else:
-                    k.colsum(dy, P.g(bias), M, Cop, ldy, accumulate=True)
                 if residual is not None:
                     self._give(residual, dy)
             self.tape.append(bwd)

@@ -170,18 +170,40 @@ class ParamStore:
         return n
 
     # ---- compute copies (call after every optimiser step / weight load)
-    def refresh(self):
+    def _tile_table(self):
+        """64x64-tile records for pdmk_transpose_tiles covering every dgrad copy (built once, lives on the device)."""
+        import numpy as np
+        recs = []
         for e in self.entries:
-            if e.kind == "vec":
+            if e.kind == "lin":
+                jobs = [(e.off, e.off, e.shape[0], e.shape[1], e.shape[1], e.shape[0])]
+            elif e.kind == "conv3":
+                co, _, ci = e.shape          # src [co][t][ci] -> dst [ci][8-t][co]
+                jobs = [(e.off + t * ci, e.off + (8 - t) * co, co, ci, 9 * ci, 9 * co) for t in range(9)]
+            else:
                 continue
-            src = self.master[e.off:e.off + e.numel]
-            if self.dtype != torch.float32:
-                k.cast_permute(src, self.w[e.off:], e.numel, 1, 1, 0)
-            if self.wt is not None:
-                if e.kind == "lin":
-                    k.cast_permute(src, self.wt[e.off:], e.shape[0], 1, e.shape[1], 1)
-                else:
-                    k.cast_permute(src, self.wt[e.off:], e.shape[0], 9, e.shape[2], 2)
+            for so, do, rows, cols, sld, dld in jobs:
+                r0s, c0s = np.arange(0, rows, 64), np.arange(0, cols, 64)
+                rr, cc = np.meshgrid(r0s, c0s, indexing="ij")
+                n = rr.size
+                t = np.zeros((n, 12), dtype=np.int64)
+                t[:, 0], t[:, 1] = so & 0xFFFFFFFF, so >> 32
+                t[:, 2], t[:, 3] = do & 0xFFFFFFFF, do >> 32
+                t[:, 4], t[:, 5], t[:, 6], t[:, 7] = rows, cols, sld, dld
+                t[:, 8], t[:, 9] = rr.ravel(), cc.ravel()
+                recs.append(t)
+        tab = np.concatenate(recs, 0)
+        tab = np.where(tab >= 2 ** 31, tab - 2 ** 32, tab).astype(np.int32)
+        return torch.from_numpy(tab).to(self.master.device), tab.shape[0]
+
+    def refresh(self, w_is_fresh=False):
+        """master -> w (cast) -> wt (tiled transposes), two launches.  `w_is_fresh`: the fused AdamW already wrote w."""
+        if self.dtype != torch.float32 and not w_is_fresh:
+            k.cast_permute(self.master, self.w, self.total, 1, 1, 0)
+        if self.wt is not None:
+            if not hasattr(self, "_tiles"):
+                self._tiles = self._tile_table()
+            k.transpose_tiles(self.w, self.wt, self._tiles[0], self._tiles[1])
 
     # ---- state dict interchange (diffusers names, pruned shapes)
     @torch.no_grad()

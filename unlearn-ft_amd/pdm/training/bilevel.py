@@ -47,10 +47,11 @@ class FusedAdamW:
         self.lr_dev.fill_(lr)
         self.bc_dev.copy_(torch.tensor([1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t]))
         s = self.store
+        fused = s.dtype == torch.bfloat16
         k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
-                self.wd, self.bc_dev, grad_scale, zero_grad)
+                self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
         self.sched_k += self.sched_mult
-        s.refresh()
+        s.refresh(w_is_fresh=fused)
         return lr
 
     def state_dict(self):
