@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--tiny", action="store_true", help="tiny topology (debug only; result is NOT the benchmark)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--no_graph", action="store_true", help="eager Python launches instead of hipGraph replay")
     return p.parse_args()
 
 
@@ -84,7 +85,7 @@ def main():
     from pdm import _pdmk as k
     from pdm.models.unet.spec import UNetConfig, arch_vector_for_budget, plan_macs
     from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
-    from pdm.training.bilevel import BilevelStepper
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
 
     cfg = UNetConfig.tiny() if a.tiny else UNetConfig.sd21()
     T = 13 if a.tiny else 77
@@ -118,10 +119,21 @@ def main():
         st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], empty)
         st.optimizer_step(upper=True)
 
+    graphs = None
+    if not a.no_graph:
+        graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
+        graphs.capture(bilevel=True)
+
     def bilevel_iter(i):
-        main_iter(i)
-        if (i + 1) % a.upper_freq == 0:
-            upper_iter(i)
+        d, u = data[i % nb], data[(i + 1) % nb]
+        if graphs is None:
+            main_iter(i)
+            if (i + 1) % a.upper_freq == 0:
+                upper_iter(i)
+        else:
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
+            if (i + 1) % a.upper_freq == 0:
+                graphs.upper(u["lat"], u["noise"], u["t"], u["ehs"], empty)
 
     def sync():
         if world > 1:
@@ -129,8 +141,8 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        main_iter(i)
-    if a.warmup > 0:
+        bilevel_iter(i) if graphs is not None else main_iter(i)
+    if a.warmup > 0 and graphs is None:
         upper_iter(0)         # untimed: warm the allocator for the upper step too
     sync()
     t0 = time.perf_counter()
@@ -154,8 +166,14 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - s) / n
         if world == 1:
-            extras["ms_main_step"] = round(timed(main_iter, 3) * 1e3, 2)
-            extras["ms_upper_step"] = round(timed(upper_iter, 2) * 1e3, 2)
+            if graphs is not None:
+                d0 = data[0]
+                extras["ms_main_step"] = round(timed(lambda j: graphs.main(d0["lat"], d0["noise"], d0["t"], d0["ehs"]), 3) * 1e3, 2)
+                extras["ms_upper_step"] = round(timed(lambda j: graphs.upper(d0["lat"], d0["noise"], d0["t"], d0["ehs"], empty), 2) * 1e3, 2)
+                st.defer_reduce = False
+            extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
+            extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
+        extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
         n_upper = sum(1 for i in range(a.steps) if (i + 1) % a.upper_freq == 0)
         flop_main = 2.0 * (Tm + 3 * Sm) * B
         flop_upper = 2.0 * (2 * Tm + 3 * Sm) * B

@@ -41,17 +41,26 @@ class FusedAdamW:
             return self.base_lr * min(1.0, self.sched_k / float(self.warmup))
         return self.base_lr
 
-    def step(self, grad_scale=1.0, zero_grad=True):
+    def prepare(self):
+        """Host-side part of a step (never captured in a graph): advance t, publish lr and bias corrections."""
         self.t += 1
         lr = self.current_lr()
         self.lr_dev.fill_(lr)
         self.bc_dev.copy_(torch.tensor([1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t]))
+        self.sched_k += self.sched_mult
+        return lr
+
+    def launch(self, grad_scale=1.0, zero_grad=True):
+        """Device-side part (graph-capturable): fused AdamW + refresh of the compute copies."""
         s = self.store
         fused = s.dtype == torch.bfloat16
         k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
                 self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
-        self.sched_k += self.sched_mult
         s.refresh(w_is_fresh=fused)
+
+    def step(self, grad_scale=1.0, zero_grad=True):
+        lr = self.prepare()
+        self.launch(grad_scale, zero_grad)
         return lr
 
     def state_dict(self):
@@ -133,6 +142,8 @@ class BilevelStepper:
         self.upper_opt = FusedAdamW(student.store, upper_lr, betas, eps, weight_decay, upper_warmup_steps * world,
                                     world) if bilevel else None
         self.reducer = GradReducer(student.store, bucket_mb)
+        self.defer_reduce = False
+        self._gscale = 1.0 / world
         self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused)
 
     # ------------------------------------------------------------------ pieces
@@ -163,9 +174,17 @@ class BilevelStepper:
                 k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
 
     def _backward_and_reduce(self):
+        if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between two graphs
+            self.student.engine.grad_ready_cb = None
+            self.student.engine.backward()
+            return 1.0 / self.world
         self.reducer.begin()
         self.student.engine.grad_ready_cb = self.reducer.ready_down_to
         self.student.engine.backward()
+        return self.reducer.finish()
+
+    def reduce_now(self):
+        self.reducer.begin()
         return self.reducer.finish()
 
     # ------------------------------------------------------------------ steps
@@ -254,3 +273,84 @@ class BilevelStepper:
         if upper:
             return w["up_dist"] * s + w["up_block"] * b, 0.0, s, b
         return w["diff"] * d + w["block"] * b + w["dist"] * s, d, s, b
+
+
+class GraphedBilevel:
+    """hipGraph replay of the bilevel iteration (launch-bound Python loop -> 4 captured graphs):
+         g_main  = forward diffusion + teacher fwd + student fwd/bwd + loss heads      (main step)
+         g_opt   = fused AdamW + weight-copy refresh                                   (main optimiser)
+         g_upper / g_uopt = the same for the concept-suppression step and its optimiser
+       Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
+       with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
+
+    def __init__(self, stepper, B, C, H, W, T, ctx):
+        self.st = stepper
+        dev = stepper.dev
+        self.lat = torch.zeros(B, C, H, W, device=dev)
+        self.noise = torch.zeros(B, C, H, W, device=dev)
+        self.t = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.ehs = torch.zeros(B, T, ctx, device=dev)
+        self.empty = torch.zeros(B, T, ctx, device=dev)
+        self.g_main = self.g_opt = self.g_upper = self.g_uopt = None
+
+    def _load(self, lat, noise, t, ehs, empty=None):
+        self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
+        if empty is not None:
+            self.empty.copy_(empty)
+
+    def capture(self, bilevel=True):
+        st = self.st
+        st.defer_reduce = True
+        # the eager warm-up below really runs the optimiser kernels: snapshot the training state and put it back after
+        store = st.student.store
+        opts = [o for o in (st.opt, st.upper_opt) if o is not None]
+        snap = [store.master.clone(), store.grad.clone()] + [t_.clone() for o in opts for t_ in (o.m, o.v)]
+        # eager warm-up on a side stream (allocator + lazy tables), as torch.cuda.graphs requires
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st.main_step(self.lat, self.noise, self.t, self.ehs)
+            st.opt.launch(st._gscale)
+            if bilevel:
+                st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
+                st.upper_opt.launch(st._gscale)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_main):
+            st.main_step(self.lat, self.noise, self.t, self.ehs)
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            st.opt.launch(st._gscale)
+        if bilevel:
+            self.g_upper = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_upper):
+                st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
+            self.g_uopt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_uopt):
+                st.upper_opt.launch(st._gscale)
+        torch.cuda.synchronize()
+        store.master.copy_(snap[0]); store.grad.copy_(snap[1])
+        for i, o in enumerate(opts):
+            o.m.copy_(snap[2 + 2 * i]); o.v.copy_(snap[3 + 2 * i])
+        del snap
+        store.refresh()
+        torch.cuda.synchronize()
+
+    def main(self, lat, noise, t, ehs):
+        self._load(lat, noise, t, ehs)
+        self.g_main.replay()
+        if self.st.world > 1:
+            self.st.reduce_now()
+        lr = self.st.opt.prepare()
+        self.g_opt.replay()
+        return lr
+
+    def upper(self, lat, noise, t, ehs, empty):
+        self._load(lat, noise, t, ehs, empty)
+        self.g_upper.replay()
+        if self.st.world > 1:
+            self.st.reduce_now()
+        lr = self.st.upper_opt.prepare()
+        self.g_uopt.replay()
+        return lr
