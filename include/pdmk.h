@@ -43,7 +43,8 @@ int pdmk_version(void);
  *         0: stride 1   iy=oy+ky-1         1: stride 2   iy=2*oy+ky-1
  *         2: nearest-x2 upsample fused: vy=oy+ky-1 in [0,2Hi) -> iy=vy>>1
  *         3: transposed stride 2 (dgrad of mode 1): vy=oy+ky-1 even, iy=vy/2 < Hi
- * K, lda/ldb/conv_ld, conv_ci must be multiples of 8 (bf16) / 4 (fp32); A/B base pointers 16-byte aligned.
+ * A loader thread moves 64 contiguous bytes: K (rowk/conv), M and N (colk) and conv_ci must be multiples of 32 (bf16) /
+ * 16 (fp32); lda/ldb/conv_ld multiples of 8 / 4; A/B base pointers 16-byte aligned; each operand < 2 GiB.
  * out_f32: C is float regardless of dtype (parameter gradients).  splitk>1: C must be float and pre-zeroed/accumulating
  * (partials are combined with float atomics).  accumulate: C += result.
  */

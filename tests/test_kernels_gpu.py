@@ -30,7 +30,7 @@ def conv_w_pack(w):   # [Co,Ci,3,3] -> [Co, 9*Ci]
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(200, 136, 72), (128, 128, 32), (1, 8, 8), (515, 320, 1024)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 32), (1, 8, 32), (515, 320, 1024)])
 def test_gemm_linear(dev, dn, M, N, K):
     from pdm import _pdmk as k
     torch.manual_seed(0)
@@ -59,7 +59,7 @@ def test_gemm_conv_fwd_modes(dev, dn, mode):
     from pdm import _pdmk as k
     torch.manual_seed(1)
     dt = DT[dn]
-    Bn, Ci, Co, Hs = 2, 24, 40, 10
+    Bn, Ci, Co, Hs = 2, 32, 40, 10
     x = rnd((Bn, Hs, Hs, Ci), dev, dt)          # NHWC source
     w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
     xn = x.float().permute(0, 3, 1, 2)
@@ -87,7 +87,7 @@ def test_gemm_wgrad_linear(dev, dn, splitk):
     from pdm import _pdmk as k
     torch.manual_seed(2)
     dt = DT[dn]
-    P, No, Ki = 300, 72, 136            # P pixels (reduction), dW [No, Ki]
+    P, No, Ki = 300, 96, 160            # P pixels (reduction), dW [No, Ki]
     dY, X = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
     dW = torch.zeros(No, Ki, device=dev)
     db = torch.ones(No, device=dev)
@@ -103,7 +103,7 @@ def test_gemm_wgrad_conv(dev, dn, mode):
     from pdm import _pdmk as k
     torch.manual_seed(3)
     dt = DT[dn]
-    Bn, Ci, Co, Hs = 2, 16, 24, 8
+    Bn, Ci, Co, Hs = 2, 32, 64, 8
     x = rnd((Bn, Hs, Hs, Ci), dev, dt)
     xn = x.float().permute(0, 3, 1, 2).requires_grad_(False)
     w = torch.zeros(Co, Ci, 3, 3, device=dev, requires_grad=True)
@@ -130,7 +130,7 @@ def test_conv_dgrad_via_cast_permute(dev, dn):
     from pdm import _pdmk as k
     torch.manual_seed(4)
     dt = DT[dn]
-    Bn, Ci, Co, Hs = 2, 16, 24, 8
+    Bn, Ci, Co, Hs = 2, 32, 64, 8
     w = torch.randn(Co, Ci, 3, 3, device=dev) * (9 * Ci) ** -0.5
     wp = conv_w_pack(w)                                   # fp32 master layout [Co, 9, Ci]
     wd = torch.zeros(Ci, 9 * Co, device=dev, dtype=dt)

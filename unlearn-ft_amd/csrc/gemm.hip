@@ -3,8 +3,10 @@
 // Workgroup = 256 threads = 4 waves (2x2), tile 128x128, K-step 64 (bf16) / 32 (fp32); each wave owns a 64x64
 // sub-tile as 4x4 MFMA 16x16 accumulators (32 bf16 MFMAs per barrier).  Operands are staged global -> registers -> LDS
 // (double buffered, one barrier per K-step); the next tile's 8 x 16-byte loads per thread are issued BEFORE the current
-// tile's MFMAs and consumed (zero-filled + written to LDS) after them, so HBM/L2 latency hides under the matrix work.
-// The register hop is what makes zero-filled halos (conv padding), tails and the four gather geometries free.
+// tile's MFMAs and written to LDS after them, so HBM/L2 latency hides under the matrix work.
+// Every thread owns ONE tile row per operand and loads 64 contiguous bytes of it with four buffer_load_dwordx4 that share
+// one 32-bit offset (+ immediates): conv padding, M/N/K tails and gather holes are expressed as an out-of-range offset,
+// which the buffer unit zero-fills in hardware - no predicate registers, no selects, ~10 VALU per K-step for addressing.
 // Gather index math is incremental (no integer division in the K loop): each thread keeps its (tap, ci) / pixel
 // coordinates and advances them by one K-step.  Reduction-major operands (wgrad) stay in memory order in LDS and are
 // transposed by ds_read_b64_tr_b16 on the way into the MFMA fragments.  The MFMA is issued with operands swapped
@@ -22,11 +24,11 @@ template <typename T> struct TileCfg {
     static constexpr int BK = 8 * CH;                   // 64 bf16 / 32 fp32: 8 chunks per tile row
     static constexpr int RS_ROWK = BK + CH;             // 144-byte rows
     static constexpr int RS_COLK = 128 + 16;
-    static constexpr int CPR = 128 / CH;                // chunks per 128-wide row (colk layouts)
-    static constexpr int KROW_STEP = NTHREADS / CPR;    // 16 / 8
+    static constexpr int G4 = 4 * CH;                   // elements one thread loads per operand (64 bytes)
+    static constexpr int GPR = 128 / G4;                // thread groups per 128-wide row (colk layouts): 4 / 8
     static_assert(BM * RS_ROWK * sizeof(T) == OPERAND_BYTES, "rowk tile bytes");
     static_assert(BK * RS_COLK * sizeof(T) == OPERAND_BYTES, "colk tile bytes");
-    static_assert(4 * KROW_STEP == BK, "4 k-rows per thread");
+    static_assert(NTHREADS / GPR == BK && 2 * G4 == BK, "one tile row per thread");
 };
 
 struct ConvGeom {
@@ -48,10 +50,12 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
     return ok ? (b * g.hi + iy) * g.wi + ix : -1;
 }
 
-__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any operand (operands are < 2 GiB): buffer loads return 0
 
 template <typename T, int AMODE, int BMODE, int CMODE>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo) {
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
+                                                         unsigned b_bytes) {
     typedef TileCfg<T> TC;
     typedef Mma<T> MM;
     constexpr int CH = TC::CH, BK = TC::BK;
@@ -69,176 +73,120 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
     const int kt1 = min(nk_total, kt0 + per);
     if (kt0 >= kt1) return;
 
-    const T* __restrict__ Ap = reinterpret_cast<const T*>(g.A);
-    const T* __restrict__ Bp = reinterpret_cast<const T*>(g.B);
+    constexpr int ESZ = sizeof(T), G4 = TC::G4;
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
     const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld, lg_wo, lg_howo};
 
-    // ---------------------------------------------------------------- per-thread loader state
-    // rowk-type operands: 4 rows (r + 32 s), one fixed 16-byte k-chunk
-    const int lr = tid >> 3, kc = (tid & 7) * CH;
-    // colk-type operands: 4 k-rows (kr + KROW_STEP s), one fixed column chunk
-    const int ckr = tid / TC::CPR, cmc = (tid % TC::CPR) * CH;
+    // ---------------------------------------------------------------- per-thread loader state (one row per operand)
+    const int lr = tid >> 1, lq = (tid & 1) * G4;              // rowk-type: tile row, element offset inside the k-tile
+    const int ckr = tid / TC::GPR, cq = (tid % TC::GPR) * G4;  // colk-type: k-row inside the tile, column offset
 
-    long a_off[4] = {-1, -1, -1, -1};    // rowk: element offset of the row start (or -1)
-    int a_b[4] = {-1, -1, -1, -1}, a_oy[4] = {0, 0, 0, 0}, a_ox[4] = {0, 0, 0, 0};   // conv: output pixel coords
-    int a_tap = 0, a_ci = 0;             // conv: (tap, ci) of this thread's chunk in the CURRENT k-tile
+    unsigned a_base = OOB;                 // rowk: byte offset of the row start
+    int a_b = -1, a_oy = 0, a_ox = 0;      // conv: output pixel of this row
+    int a_tap = 0, a_ci = 0;               // conv: (tap, ci) of this thread's 64 bytes in the CURRENT k-tile
     if (AMODE == PDMK_A_ROWK) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int m = m0 + lr + 32 * s;
-            a_off[s] = m < g.M ? (long)m * g.lda : -1;
-        }
+        const int m = m0 + lr;
+        if (m < g.M) a_base = (unsigned)m * (unsigned)g.lda * ESZ;
     } else if (AMODE == PDMK_A_CONV) {
         const int hw = cg.ho * cg.wo;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int m = m0 + lr + 32 * s;
-            if (m < g.M) {
-                a_b[s] = m / hw;
-                const int rem = m - a_b[s] * hw;
-                a_oy[s] = rem / cg.wo;
-                a_ox[s] = rem - a_oy[s] * cg.wo;
-            }
+        const int m = m0 + lr;
+        if (m < g.M) {
+            a_b = m / hw;
+            const int rem = m - a_b * hw;
+            a_oy = rem / cg.wo;
+            a_ox = rem - a_oy * cg.wo;
         }
-        const int k = kt0 * BK + kc;
+        const int k = kt0 * BK + lq;
         a_tap = k / cg.ci;
         a_ci = k - a_tap * cg.ci;
     }
-    long b_off[4] = {-1, -1, -1, -1};
+    unsigned b_base = OOB;
     int b_tap = 0, b_ci = 0;
     if (BMODE == PDMK_B_ROWK) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int n = n0 + lr + 32 * s;
-            b_off[s] = n < g.N ? (long)n * g.ldb : -1;
-        }
+        const int n = n0 + lr;
+        if (n < g.N) b_base = (unsigned)n * (unsigned)g.ldb * ESZ;
     } else if (BMODE == PDMK_B_COLK_CONV) {
-        const int col = n0 + cmc;
+        const int col = n0 + cq;
         b_tap = col / cg.ci;
         b_ci = col - b_tap * cg.ci;
     }
 
-    // Loads are always issued from a valid address (the operand base when predicated off); the zero-fill is applied
-    // when the registers go to LDS, AFTER the MFMAs: a data select right behind the load would force vmcnt(0) early.
-    uint4 ra[4], rb[4];
-    unsigned pmask = 0;   // bit s: ra[s] valid, bit 4+s: rb[s] valid
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    u32x4 ra[4], rb[4];
     // fused bias gradient (wgrad only): the blocks of the first n-tile also sum their A = dY tiles over the reduction
-    // dim; every tile passes through store_tiles exactly once, which is where the (zero-filled) registers are summed.
+    // dim; every tile passes through store_tiles exactly once, which is where the registers are summed.
     const bool do_colsum = (AMODE == PDMK_A_COLK) && g.colsum_out != nullptr && n0 == 0;
-    float csum[CH];
+    float csum[G4];
 #pragma unroll
-    for (int e = 0; e < CH; ++e) csum[e] = 0.f;
+    for (int e = 0; e < G4; ++e) csum[e] = 0.f;
+
+    auto load4 = [&](u32x4* r, const decltype(rsrcA)& rs, unsigned voff) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u * j), 0, 0);
+    };
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
-        pmask = 0;
         // ---- A
         if (AMODE == PDMK_A_ROWK) {
-            const int k = k0 + kc;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bool ok = a_off[s] >= 0 && k < g.K;
-                pmask |= (unsigned)ok << s;
-                ra[s] = ld16(ok ? Ap + a_off[s] + k : Ap);
-            }
+            const int k = k0 + lq;
+            load4(ra, rsrcA, (a_base != OOB && k < g.K) ? a_base + (unsigned)k * ESZ : OOB);
         } else if (AMODE == PDMK_A_CONV) {
-            const bool kok = k0 + kc < g.K;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int px = (kok && a_b[s] >= 0) ? conv_src_pixel<CMODE>(cg, a_b[s], a_oy[s], a_ox[s], a_tap) : -1;
-                pmask |= (unsigned)(px >= 0) << s;
-                ra[s] = ld16(px >= 0 ? Ap + (long)px * cg.ld + a_ci : Ap);
-            }
+            const int px = (k0 + lq < g.K && a_b >= 0) ? conv_src_pixel<CMODE>(cg, a_b, a_oy, a_ox, a_tap) : -1;
+            load4(ra, rsrcA, px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)a_ci) * ESZ : OOB);
             a_ci += BK;                                   // advance this thread's (tap, ci) by one k-tile
             while (a_ci >= cg.ci) { a_ci -= cg.ci; ++a_tap; }
         } else {
-            const int col = m0 + cmc;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kr = k0 + ckr + TC::KROW_STEP * s;
-                const bool ok = kr < g.K && col < g.M;
-                pmask |= (unsigned)ok << s;
-                ra[s] = ld16(ok ? Ap + (long)kr * g.lda + col : Ap);
-            }
+            const int kr = k0 + ckr, col = m0 + cq;
+            load4(ra, rsrcA, (kr < g.K && col < g.M) ? ((unsigned)kr * (unsigned)g.lda + (unsigned)col) * ESZ : OOB);
         }
         // ---- B
         if (BMODE == PDMK_B_ROWK) {
-            const int k = k0 + kc;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bool ok = b_off[s] >= 0 && k < g.K;
-                pmask |= (unsigned)ok << (4 + s);
-                rb[s] = ld16(ok ? Bp + b_off[s] + k : Bp);
-            }
+            const int k = k0 + lq;
+            load4(rb, rsrcB, (b_base != OOB && k < g.K) ? b_base + (unsigned)k * ESZ : OOB);
         } else if (BMODE == PDMK_B_COLK) {
-            const int col = n0 + cmc;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kr = k0 + ckr + TC::KROW_STEP * s;
-                const bool ok = kr < g.K && col < g.N;
-                pmask |= (unsigned)ok << (4 + s);
-                rb[s] = ld16(ok ? Bp + (long)kr * g.ldb + col : Bp);
-            }
+            const int kr = k0 + ckr, col = n0 + cq;
+            load4(rb, rsrcB, (kr < g.K && col < g.N) ? ((unsigned)kr * (unsigned)g.ldb + (unsigned)col) * ESZ : OOB);
         } else {
-            const int col = n0 + cmc;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kr = k0 + ckr + TC::KROW_STEP * s;
-                int px = -1;
-                if (kr < g.K && col < g.N) {
-                    int b, oy, ox;
-                    if (cg.lg_wo >= 0) {          // power-of-two image: shifts instead of divisions
-                        b = kr >> cg.lg_howo;
-                        const int rem = kr & ((1 << cg.lg_howo) - 1);
-                        oy = rem >> cg.lg_wo;
-                        ox = rem & ((1 << cg.lg_wo) - 1);
-                    } else {
-                        const int hw = cg.ho * cg.wo;
-                        b = kr / hw;
-                        const int rem = kr - b * hw;
-                        oy = rem / cg.wo;
-                        ox = rem - oy * cg.wo;
-                    }
-                    px = conv_src_pixel<CMODE>(cg, b, oy, ox, b_tap);
+            const int kr = k0 + ckr, col = n0 + cq;
+            int px = -1;
+            if (kr < g.K && col < g.N) {
+                int b, oy, ox;
+                if (cg.lg_wo >= 0) {          // power-of-two image: shifts instead of divisions
+                    b = kr >> cg.lg_howo;
+                    const int rem = kr & ((1 << cg.lg_howo) - 1);
+                    oy = rem >> cg.lg_wo;
+                    ox = rem & ((1 << cg.lg_wo) - 1);
+                } else {
+                    const int hw = cg.ho * cg.wo;
+                    b = kr / hw;
+                    const int rem = kr - b * hw;
+                    oy = rem / cg.wo;
+                    ox = rem - oy * cg.wo;
                 }
-                pmask |= (unsigned)(px >= 0) << (4 + s);
-                rb[s] = ld16(px >= 0 ? Bp + (long)px * cg.ld + b_ci : Bp);
+                px = conv_src_pixel<CMODE>(cg, b, oy, ox, b_tap);
             }
+            load4(rb, rsrcB, px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)b_ci) * ESZ : OOB);
         }
     };
 
     auto store_tiles = [&](int buf) {
         T* As = reinterpret_cast<T*>(smem[buf][0]);
         T* Bs = reinterpret_cast<T*>(smem[buf][1]);
+        T* ad = (AMODE == PDMK_A_COLK) ? As + ckr * TC::RS_COLK + cq : As + lr * TC::RS_ROWK + lq;
+        T* bd = (BMODE != PDMK_B_ROWK) ? Bs + ckr * TC::RS_COLK + cq : Bs + lr * TC::RS_ROWK + lq;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (!((pmask >> s) & 1)) ra[s] = zero4;
-            if (!((pmask >> (4 + s)) & 1)) rb[s] = zero4;
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<u32x4*>(ad + j * CH) = ra[j];
+            *reinterpret_cast<u32x4*>(bd + j * CH) = rb[j];
         }
-        if (AMODE == PDMK_A_COLK) {
+        if (do_colsum) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                *reinterpret_cast<uint4*>(As + (ckr + TC::KROW_STEP * s) * TC::RS_COLK + cmc) = ra[s];
-            if (do_colsum) {
+            for (int j = 0; j < 4; ++j) {
+                const T* v = reinterpret_cast<const T*>(&ra[j]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const T* v = reinterpret_cast<const T*>(&ra[s]);
-#pragma unroll
-                    for (int e = 0; e < CH; ++e) csum[e] += to_f32(v[e]);
-                }
+                for (int e = 0; e < CH; ++e) csum[j * CH + e] += to_f32(v[e]);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(As + (lr + 32 * s) * TC::RS_ROWK + kc) = ra[s];
-        }
-        if (BMODE == PDMK_B_ROWK) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) *reinterpret_cast<uint4*>(Bs + (lr + 32 * s) * TC::RS_ROWK + kc) = rb[s];
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                *reinterpret_cast<uint4*>(Bs + (ckr + TC::KROW_STEP * s) * TC::RS_COLK + cmc) = rb[s];
         }
     };
 
@@ -278,14 +226,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         cur ^= 1;
     }
 
-    if (do_colsum) {      // combine the KROW_STEP k-row groups through LDS (all tile reads are behind the last barrier)
+    if (do_colsum) {      // combine the BK k-rows through LDS (all tile reads are behind the last barrier)
         float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int e = 0; e < CH; ++e) red[ckr * 128 + cmc + e] = csum[e];
+        for (int e = 0; e < G4; ++e) red[ckr * 128 + cq + e] = csum[e];
         __syncthreads();
         if (tid < 128 && m0 + tid < g.M) {
             float s = 0.f;
-            for (int j = 0; j < TC::KROW_STEP; ++j) s += red[j * 128 + tid];
+            for (int j = 0; j < BK; ++j) s += red[j * 128 + tid];
             unsafeAtomicAdd(g.colsum_out + m0 + tid, s);
         }
     }
@@ -388,7 +336,16 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
         lg_howo = ilog2_exact(g.conv_ho * g.conv_wo);
         if (lg_wo < 0 || lg_howo < 0) lg_wo = lg_howo = -1;
     }
-#define PDMK_GO(AM, BMD, CM) hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM>), grid, block, 0, st, g, lg_wo, lg_howo)
+    const long esz = sizeof(T);
+    const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * esz;
+    const long a_bytes = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * esz
+                       : g.a_mode == PDMK_A_CONV ? conv_bytes : ((long)(g.K - 1) * g.lda + g.M) * esz;
+    const long b_bytes = g.b_mode == PDMK_B_ROWK ? ((long)(g.N - 1) * g.ldb + g.K) * esz
+                       : g.b_mode == PDMK_B_COLK ? ((long)(g.K - 1) * g.ldb + g.N) * esz : conv_bytes;
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -1;     // 32-bit buffer offsets
+#define PDMK_GO(AM, BMD, CM)                                                                               \
+    hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM>), grid, block, 0, st, g, lg_wo, lg_howo, (unsigned)a_bytes, \
+                       (unsigned)b_bytes)
     if (g.a_mode == PDMK_A_ROWK && g.b_mode == PDMK_B_ROWK) PDMK_GO(PDMK_A_ROWK, PDMK_B_ROWK, 0);
     else if (g.a_mode == PDMK_A_CONV && g.b_mode == PDMK_B_ROWK) {
         switch (g.conv_mode) {
@@ -417,16 +374,17 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (!a || !a->A || !a->B || !a->C) return -1;
     const pdmk_gemm_args& g = *a;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
-    const int ch = g.dtype == PDMK_BF16 ? 8 : 4;
+    const int ch = g.dtype == PDMK_BF16 ? 8 : 4;     // elements per 16 bytes
+    const int g4 = 4 * ch;                             // a thread moves 64 contiguous bytes: 32 bf16 / 16 fp32
     if (g.dtype != PDMK_BF16 && g.dtype != PDMK_F32) return -2;
-    if (g.a_mode != PDMK_A_COLK && (g.K % ch)) return -1;   // reduction-major operands predicate every k-row
+    if (g.a_mode != PDMK_A_COLK && (g.K % g4)) return -1;   // reduction-major operands predicate every k-row
     if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) return -1;
     if (g.a_mode == PDMK_A_ROWK && (g.lda % ch)) return -1;
-    if (g.a_mode == PDMK_A_COLK && ((g.lda % ch) || (g.M % ch))) return -1;
+    if (g.a_mode == PDMK_A_COLK && ((g.lda % ch) || (g.M % g4))) return -1;
     if (g.b_mode == PDMK_B_ROWK && (g.ldb % ch)) return -1;
-    if (g.b_mode == PDMK_B_COLK && ((g.ldb % ch) || (g.N % ch))) return -1;
+    if (g.b_mode == PDMK_B_COLK && ((g.ldb % ch) || (g.N % g4))) return -1;
     if (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) {
-        if (g.conv_ci <= 0 || (g.conv_ci % ch) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 3) return -1;
+        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 3) return -1;
         if (g.conv_b <= 0 || g.conv_hi <= 0 || g.conv_wi <= 0 || g.conv_ho <= 0 || g.conv_wo <= 0) return -1;
         const long px = (long)g.conv_b * g.conv_ho * g.conv_wo;
         if (px >= (1L << 30) || (long)g.conv_b * g.conv_hi * g.conv_wi >= (1L << 30)) return -1;   // 32-bit pixel ids
@@ -443,4 +401,4 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     return g.dtype == PDMK_BF16 ? launch<bf16>(g, st) : launch<float>(g, st);
 }
 
-extern "C" int pdmk_version(void) { return 101; }
+extern "C" int pdmk_version(void) { return 102; }

@@ -13,7 +13,7 @@ import torch
 
 from ... import _pdmk as k
 from .params import ParamStore
-from .spec import UNetConfig, pad8
+from .spec import UNetConfig, padc
 
 
 class Act:
@@ -307,8 +307,8 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ whole model
     def forward(self, x, timesteps, ehs, B, H, W, train):
-        """x: [B*H*W, pad8(in_channels)] NHWC rows in self.dtype; timesteps int64 [B]; ehs: [B*T, ctx] in self.dtype.
-        Returns (pred Act [B*H*W, pad8(out_channels)], acts {d0..,m,u0..: Act})."""
+        """x: [B*H*W, padc(in_channels)] NHWC rows in self.dtype; timesteps int64 [B]; ehs: [B*T, ctx] in self.dtype.
+        Returns (pred Act [B*H*W, padc(out_channels)], acts {d0..,m,u0..: Act})."""
         cfg = self.cfg
         self.train = train
         self.tape = []

@@ -17,7 +17,7 @@ from typing import List, Tuple
 import torch
 
 from ... import _pdmk as k
-from .spec import UNetConfig, pad8
+from .spec import UNetConfig, padc
 
 
 @dataclass
@@ -25,9 +25,20 @@ class Entry:
     key: str                              # arena key, e.g. "mid_block.resnets.0.conv1.weight"
     kind: str                             # conv3 | lin | vec
     shape: Tuple[int, ...]                # packed shape
-    srcs: List[Tuple[str, int]]           # [(state-dict name, rows)] concatenated along dim 0
+    srcs: List[Tuple]                     # [(state-dict name, rows[, dst_row0, src_row0])]: row blocks of dim 0
     logical: Tuple[int, ...]              # logical (unpadded) shape of the concatenation: (n, k) | (co, ci) | (n,)
     off: int = 0
+
+    def __post_init__(self):
+        norm, r = [], 0
+        for t in self.srcs:
+            if len(t) == 2:
+                norm.append((t[0], t[1], r, 0))
+                r += t[1]
+            else:
+                norm.append(tuple(t))
+                r = t[2] + t[1]
+        self.srcs = norm
 
     @property
     def numel(self):
@@ -38,17 +49,23 @@ class Entry:
 
 
 def _conv(key, co, ci):
-    return Entry(key + ".weight", "conv3", (pad8(co), 9, pad8(ci)), [(key + ".weight", co)], (co, ci))
+    return Entry(key + ".weight", "conv3", (padc(co), 9, padc(ci)), [(key + ".weight", co)], (co, ci))
 
 
-def _lin(key, srcs, k_in, suffix=".weight"):
-    n = sum(r for _, r in srcs)
-    return Entry(key + suffix, "lin", (pad8(n), pad8(k_in)), srcs, (n, k_in))
+def _lin(key, srcs, k_in, suffix=".weight", rows_p=None):
+    n = sum(t[1] for t in srcs)
+    return Entry(key + suffix, "lin", (rows_p or padc(n), padc(k_in)), srcs, (n, k_in))
 
 
-def _vec(key, srcs):
-    n = sum(r for _, r in srcs)
-    return Entry(key, "vec", (pad8(n),), srcs, (n,))
+def _vec(key, srcs, rows_p=None):
+    n = sum(t[1] for t in srcs)
+    return Entry(key, "vec", (rows_p or padc(n),), srcs, (n,))
+
+
+def _geglu_rows(name, ff):
+    """GEGLU proj rows [hidden | gate] (blocks.py:55): each half is padded separately so the packed row layout is
+    [h (padc(ff)) | g (padc(ff))] and the GEGLU kernel sees F = padc(ff)."""
+    return [(name, ff, 0, 0), (name, ff, padc(ff), ff)]
 
 
 def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
@@ -97,8 +114,8 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
                      cfg.cross_attention_dim),
                 _lin(f"{t}.attn2.to_out.0", [(f"{t}.attn2.to_out.0.weight", c)], d2),
                 _vec(f"{t}.attn2.to_out.0.bias", [(f"{t}.attn2.to_out.0.bias", c)]),
-                _lin(f"{t}.ff.net.0.proj", [(f"{t}.ff.net.0.proj.weight", 2 * ff)], c),
-                _vec(f"{t}.ff.net.0.proj.bias", [(f"{t}.ff.net.0.proj.bias", 2 * ff)]),
+                _lin(f"{t}.ff.net.0.proj", _geglu_rows(f"{t}.ff.net.0.proj.weight", ff), c, rows_p=2 * padc(ff)),
+                _vec(f"{t}.ff.net.0.proj.bias", _geglu_rows(f"{t}.ff.net.0.proj.bias", ff), rows_p=2 * padc(ff)),
                 _lin(f"{t}.ff.net.2", [(f"{t}.ff.net.2.weight", c)], ff),
                 _vec(f"{t}.ff.net.2.bias", [(f"{t}.ff.net.2.bias", c)]),
                 _lin(f"{p}.proj_out", [(f"{p}.proj_out.weight", c)], c),
@@ -210,30 +227,25 @@ class ParamStore:
     def load_state_dict(self, sd, strict=True):
         seen = set()
         for e in self.entries:
-            parts = []
-            for name, rows in e.srcs:
+            packed = torch.zeros(e.shape)
+            for name, rows, d0, s0 in e.srcs:
                 if name not in sd:
                     raise KeyError(f"missing key {name}")
                 t = sd[name].detach().to(torch.float32).cpu()
                 seen.add(name)
+                total = sum(r for n_, r, _, _ in e.srcs if n_ == name)
                 if e.kind == "conv3":
-                    assert t.dim() == 4 and t.shape[0] == rows and t.shape[1] == e.logical[1] and t.shape[2:] == (3, 3), \
-                        f"{name}: got {tuple(t.shape)}, expected ({rows},{e.logical[1]},3,3)"
-                    t = t.permute(0, 2, 3, 1)
+                    assert t.dim() == 4 and t.shape[0] == total and t.shape[1] == e.logical[1] and t.shape[2:] == (3, 3), \
+                        f"{name}: got {tuple(t.shape)}, expected ({total},{e.logical[1]},3,3)"
+                    t = t.permute(0, 2, 3, 1)[s0:s0 + rows]
+                    packed[d0:d0 + rows, :, :t.shape[3]] = t.reshape(rows, 9, t.shape[3])
                 elif e.kind == "lin":
                     t = t.reshape(t.shape[0], -1)
-                    assert tuple(t.shape) == (rows, e.logical[1]), f"{name}: got {tuple(t.shape)}, expected {(rows, e.logical[1])}"
+                    assert tuple(t.shape) == (total, e.logical[1]), f"{name}: got {tuple(t.shape)}, expected {(total, e.logical[1])}"
+                    packed[d0:d0 + rows, :t.shape[1]] = t[s0:s0 + rows]
                 else:
-                    assert tuple(t.shape) == (rows,), f"{name}: got {tuple(t.shape)}, expected {(rows,)}"
-                parts.append(t)
-            t = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-            packed = torch.zeros(e.shape)
-            if e.kind == "conv3":
-                packed[:t.shape[0], :, :t.shape[3]] = t.reshape(t.shape[0], 9, t.shape[3])
-            elif e.kind == "lin":
-                packed[:t.shape[0], :t.shape[1]] = t
-            else:
-                packed[:t.shape[0]] = t
+                    assert tuple(t.shape) == (total,), f"{name}: got {tuple(t.shape)}, expected {(total,)}"
+                    packed[d0:d0 + rows] = t[s0:s0 + rows]
             self.master[e.off:e.off + e.numel].copy_(packed.reshape(-1))
         if strict:
             extra = set(sd) - seen
@@ -244,20 +256,21 @@ class ParamStore:
     @torch.no_grad()
     def state_dict(self, arena=None):
         arena = self.master if arena is None else arena
-        out = {}
+        pieces = {}
         for e in self.entries:
             t = arena[e.off:e.off + e.numel].detach().cpu().reshape(e.shape)
-            r0 = 0
-            for name, rows in e.srcs:
+            for name, rows, d0, s0 in e.srcs:
                 if e.kind == "conv3":
-                    out[name] = t[r0:r0 + rows, :, :e.logical[1]].reshape(rows, 3, 3, e.logical[1]).permute(0, 3, 1, 2).contiguous()
+                    v = t[d0:d0 + rows, :, :e.logical[1]].reshape(rows, 3, 3, e.logical[1]).permute(0, 3, 1, 2).contiguous()
                 elif e.kind == "lin":
-                    w = t[r0:r0 + rows, :e.logical[1]].contiguous()
-                    out[name] = w.reshape(rows, e.logical[1], 1, 1) if name.endswith("conv_shortcut.weight") else w
+                    v = t[d0:d0 + rows, :e.logical[1]].contiguous()
+                    if name.endswith("conv_shortcut.weight"):
+                        v = v.reshape(rows, e.logical[1], 1, 1)
                 else:
-                    out[name] = t[r0:r0 + rows].clone()
-                r0 += rows
-        return out
+                    v = t[d0:d0 + rows].clone()
+                pieces.setdefault(name, []).append((s0, v))
+        return {n: (torch.cat([v for _, v in sorted(ps, key=lambda x: x[0])], 0) if len(ps) > 1 else ps[0][1])
+                for n, ps in pieces.items()}
 
     @torch.no_grad()
     def init_random(self, seed=0):
@@ -268,15 +281,16 @@ class ParamStore:
             view = self.master[e.off:e.off + e.numel].view(e.shape)
             view.zero_()
             if e.kind == "vec":
-                n = e.logical[0]
-                if e.key.endswith(".weight") and ("norm" in e.key):
-                    view[:n] = 1.0
-                elif e.key.endswith(".bias") and ("norm" not in e.key):
-                    fan = self._fan_in_of_bias(e.key)
-                    view[:n] = (torch.rand(n, generator=g, device=view.device) * 2 - 1) / fan ** 0.5
+                for _, rows, d0, _s0 in e.srcs:
+                    if e.key.endswith(".weight") and ("norm" in e.key):
+                        view[d0:d0 + rows] = 1.0
+                    elif e.key.endswith(".bias") and ("norm" not in e.key):
+                        fan = self._fan_in_of_bias(e.key)
+                        view[d0:d0 + rows] = (torch.rand(rows, generator=g, device=view.device) * 2 - 1) / fan ** 0.5
             elif e.kind == "lin":
-                n, kk = e.logical
-                view[:n, :kk] = (torch.rand(n, kk, generator=g, device=view.device) * 2 - 1) / kk ** 0.5
+                kk = e.logical[1]
+                for _, rows, d0, _s0 in e.srcs:
+                    view[d0:d0 + rows, :kk] = (torch.rand(rows, kk, generator=g, device=view.device) * 2 - 1) / kk ** 0.5
             else:
                 co, ci = e.logical
                 view[:co, :, :ci] = (torch.rand(co, 9, ci, generator=g, device=view.device) * 2 - 1) / (9 * ci) ** 0.5
@@ -288,6 +302,6 @@ class ParamStore:
             e = self.by_key[wkey]
             return e.logical[1] * (9 if e.kind == "conv3" else 1)
         for e in self.entries:          # fused projections
-            if any(n == wkey for n, _ in e.srcs):
+            if any(t_[0] == wkey for t_ in e.srcs):
                 return e.logical[1]
         return 1

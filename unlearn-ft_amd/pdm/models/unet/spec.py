@@ -17,8 +17,12 @@ import torch
 HEAD_DIM = 64
 
 
-def pad8(n):
-    return (n + 7) // 8 * 8
+CHANNEL_PAD = 32     # every channel / feature dim is zero-padded to a multiple of 32: one thread of the GEMM loaders
+                     # moves 64 contiguous bytes (32 bf16) of a tile row, so rows and conv taps are 64-byte granular
+
+
+def padc(n):
+    return (n + CHANNEL_PAD - 1) // CHANNEL_PAD * CHANNEL_PAD
 
 
 @dataclass(frozen=True)

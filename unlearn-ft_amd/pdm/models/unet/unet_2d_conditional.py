@@ -18,7 +18,7 @@ import torch
 from ... import _pdmk as k
 from .engine import UNetEngine, Act
 from .params import ParamStore, build_entries
-from .spec import UNetConfig, apply_arch_vector, gate_structure, pad8
+from .spec import UNetConfig, apply_arch_vector, gate_structure, padc
 
 _GATED_DOWN = ("CrossAttnDownBlock2DWidthHalfDepthGated", "DownBlock2DWidthHalfDepthGated",
                "CrossAttnDownBlock2D", "DownBlock2D")
@@ -173,7 +173,7 @@ class UNet2DConditionModelPruned:
         timestep = timestep.to(dev).to(torch.int64).reshape(-1)
         if timestep.numel() == 1 and B > 1:
             timestep = timestep.expand(B).contiguous()
-        cp = pad8(C)
+        cp = padc(C)
         x = torch.empty((B * H * W, cp), device=dev, dtype=self.dtype)
         k.nchw_to_nhwc(sample.to(dev, torch.float32).contiguous(), x, B, C, H * W, cp)
         ehs = encoder_hidden_states.to(dev).to(self.dtype).reshape(B * encoder_hidden_states.shape[1], -1).contiguous()

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _pdmk as k
-from ..models.unet.spec import pad8
+from ..models.unet.spec import padc
 from ..utils.metric_utils import alphas_cumprod_sd, min_snr_weight_table
 
 BLOCK_KEYS = ("d0", "d1", "d2", "d3", "m", "u0", "u1", "u2", "u3")
@@ -149,7 +149,7 @@ class BilevelStepper:
     # ------------------------------------------------------------------ pieces
     def _diffuse(self, latents, noise, timesteps, want_target):
         B, C, H, W = latents.shape
-        cp = pad8(C)
+        cp = padc(C)
         dt = self.student.dtype
         noisy = torch.empty((B * H * W, cp), device=self.dev, dtype=dt)
         target = torch.empty((B * H * W, cp), device=self.dev, dtype=torch.float32) if want_target else None
