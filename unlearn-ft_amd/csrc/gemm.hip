@@ -16,6 +16,10 @@
 
 namespace {
 
+#define PDMK_GEMM_NBUF 2
+#ifndef PDMK_GEMM_PF2
+#define PDMK_GEMM_PF2 0      // 1: two K-tiles in flight in registers (measured SLOWER on MI355X: +60-120 VGPRs), 0: one
+#endif
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
 constexpr int OPERAND_BYTES = 18432;      // 128 x 144 B  ==  64(32) k-rows x 144 elements
 
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
     typedef TileCfg<T> TC;
     typedef Mma<T> MM;
     constexpr int CH = TC::CH, BK = TC::BK;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][OPERAND_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PDMK_GEMM_NBUF][2][OPERAND_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -113,6 +117,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
     }
 
     u32x4 ra[4], rb[4];
+#if PDMK_GEMM_PF2
+    u32x4 ra2[4], rb2[4];     // second register set: two tiles in flight
+#endif
     // fused bias gradient (wgrad only): the blocks of the first n-tile also sum their A = dY tiles over the reduction
     // dim; every tile passes through store_tiles exactly once, which is where the registers are summed.
     const bool do_colsum = (AMODE == PDMK_A_COLK) && g.colsum_out != nullptr && n0 == 0;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u * j), 0, 0);
     };
 
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, u32x4* ra, u32x4* rb) {
         const int k0 = kt * BK;
         // ---- A
         if (AMODE == PDMK_A_ROWK) {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const u32x4* ra, const u32x4* rb) {
         T* As = reinterpret_cast<T*>(smem[buf][0]);
         T* Bs = reinterpret_cast<T*>(smem[buf][1]);
         T* ad = (AMODE == PDMK_A_COLK) ? As + ckr * TC::RS_COLK + cq : As + lr * TC::RS_ROWK + lq;
@@ -196,13 +203,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(kt0);
-    store_tiles(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const bool more = kt + 1 < kt1;
-        if (more) load_tiles(kt + 1);
+    auto compute = [&](int cur) {
         const T* As = reinterpret_cast<const T*>(smem[cur][0]);
         const T* Bs = reinterpret_cast<const T*>(smem[cur][1]);
 #pragma unroll
@@ -221,10 +222,44 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
         }
-        if (more) store_tiles(cur ^ 1);
+    };
+
+#if PDMK_GEMM_PF2
+    // two tiles in flight: while tile kt is multiplied out of LDS, tile kt+1 sits in one register set (written to LDS
+    // after the MFMAs) and tile kt+2 is being fetched into the other one
+    load_tiles(kt0, ra, rb);
+    if (kt0 + 1 < kt1) load_tiles(kt0 + 1, ra2, rb2);
+    store_tiles(0, ra, rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0;;) {
+        if (kt + 2 < kt1) load_tiles(kt + 2, ra, rb);
+        compute(cur);
+        if (kt + 1 < kt1) store_tiles(cur ^ 1, ra2, rb2);
+        __syncthreads();
+        cur ^= 1;
+        if (++kt >= kt1) break;
+        if (kt + 2 < kt1) load_tiles(kt + 2, ra2, rb2);
+        compute(cur);
+        if (kt + 1 < kt1) store_tiles(cur ^ 1, ra, rb);
+        __syncthreads();
+        cur ^= 1;
+        if (++kt >= kt1) break;
+    }
+#else
+    load_tiles(kt0, ra, rb);
+    store_tiles(0, ra, rb);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const bool more = kt + 1 < kt1;
+        if (more) load_tiles(kt + 1, ra, rb);
+        compute(cur);
+        if (more) store_tiles(cur ^ 1, ra, rb);
         __syncthreads();
         cur ^= 1;
     }
+#endif
 
     if (do_colsum) {      // combine the BK k-rows through LDS (all tile reads are behind the last barrier)
         float* red = reinterpret_cast<float*>(smem);
