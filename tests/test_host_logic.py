@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the product (no kernel launches): shape table vs the oracle's literal pruning, MAC counter,
+packed-arena import/export round trip, LR schedule, C-ABI surface."""
+import os
+import re
+
+import torch
+
+from pdm_ref import arch as oarch, weights as oweights, unet as ounet
+from pdm_ref.config import UNetConfig as OCfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from pdm import _pdmk
+    hdr = open(os.path.join(ROOT, "include", "pdmk.h")).read()
+    declared = set(re.findall(r"^int (pdmk_\w+)\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_pdmk.EXPORTS), declared ^ set(_pdmk.EXPORTS)
+    for name in declared:
+        assert hasattr(_pdmk._lib, name)
+    assert _pdmk.version() >= 100
+
+
+def test_structure_matches_oracle_and_reference_sizes():
+    from pdm.models.unet import spec
+    for mk, omk in ((spec.UNetConfig.tiny, OCfg.tiny), (spec.UNetConfig.sd21, OCfg.sd21)):
+        assert spec.gate_structure(mk()) == oarch.structure(omk())
+    assert spec.arch_vector_size(spec.UNetConfig.sd21()) == 1620
+    g = torch.Generator().manual_seed(0)
+    av = spec.get_random_arch_vector(0.5, spec.gate_structure(spec.UNetConfig.sd21()), g)
+    assert av.shape == (1, 1620) and all(min(abs(v), abs(v - 0.9)) < 1e-6 for v in av.unique().tolist())
+
+
+def test_plan_macs_equals_oracle_mac_counter():
+    from pdm.models.unet import spec
+    cfg, ocfg = spec.UNetConfig.tiny(), OCfg.tiny()
+    dense = oweights.init_dense_state_dict(ocfg, 0)
+    av = oarch.random_arch_vector(ocfg, 0.55, 0, drop_depth=(1, 5, 9, 12))
+    psd, info = oweights.prune_state_dict(dense, ocfg, av)
+    assert spec.plan_macs(cfg, spec.apply_arch_vector(cfg, av), 16, 13)[0] == ounet.unet_macs(psd, ocfg, info, 16, 13)
+    assert spec.plan_macs(cfg, spec.build_blocks(cfg), 16, 13)[0] == ounet.unet_macs(dense, ocfg, oweights.dense_info(ocfg), 16, 13)
+    total, by = spec.plan_macs(spec.UNetConfig.sd21(), spec.build_blocks(spec.UNetConfig.sd21()), 64, 77)
+    assert abs(total / 1e9 - 402.13) < 0.01 and abs(by["conv3x3"] / total - 0.498) < 0.002
+    av55, ratio, _ = spec.arch_vector_for_budget(spec.UNetConfig.sd21(), 0.55)
+    assert abs(ratio - 0.55) < 0.01
+
+
+def test_packed_arena_roundtrip_is_the_reference_pruning():
+    from pdm.models.unet import spec, params
+    from pdm.models.unet.unet_2d_conditional import slice_dense_state_dict
+    cfg, ocfg = spec.UNetConfig.tiny(), OCfg.tiny()
+    dense = oweights.init_dense_state_dict(ocfg, 0)
+    av = oarch.random_arch_vector(ocfg, 0.55, 0, drop_depth=(1, 5, 9, 12))
+    psd, _ = oweights.prune_state_dict(dense, ocfg, av)
+    blocks = spec.apply_arch_vector(cfg, av)
+    mine = slice_dense_state_dict(dense, cfg, blocks)
+    assert set(mine) == set(psd)
+    assert all(torch.equal(mine[k], psd[k]) for k in psd)
+    store = params.ParamStore(params.build_entries(cfg, blocks), "cpu", torch.float32, train=False)
+    store.load_state_dict(psd, refresh=False)
+    back = store.state_dict()
+    assert set(back) == set(psd) and all(torch.equal(back[k], psd[k]) for k in psd)
+    # every packed dim is a multiple of the channel pad and the padding is zero
+    for e in store.entries:
+        assert all(d % spec.CHANNEL_PAD == 0 for d in e.shape if d != 9), (e.key, e.shape)
+    logical = sum(v.numel() for v in psd.values())
+    assert store.num_logical_params() == logical
+    tot = float(sum(v.double().abs().sum() for v in psd.values()))
+    assert abs(float(store.master.double().abs().sum()) - tot) <= 1e-9 * tot        # padding is exactly zero
+
+
+def test_lr_schedule_constant_with_warmup_times_world():
+    from pdm.training.bilevel import FusedAdamW
+
+    class S:            # stand-in store: FusedAdamW only needs .master for sizing here
+        master = torch.zeros(8)
+    opt = FusedAdamW(S, lr=1e-3, warmup_steps=250 * 4, sched_mult=4)     # trainer.py:436-443 with W=4
+    lrs = []
+    for _ in range(300):
+        lrs.append(opt.current_lr())
+        opt.sched_k += opt.sched_mult
+    assert lrs[0] == 0.0 and abs(lrs[125] - 0.5e-3) < 1e-9 and lrs[250] == 1e-3 and lrs[-1] == 1e-3
+
+
+def test_cli_flags_of_reference_slurm_scripts_parse():
+    from pdm.utils.arg_utils import parse_args
+    a = parse_args(["--base_config_path", "x.yaml", "--cache_dir", "/c", "--wandb_run_name", "r", "--pruning_ckpt_dir",
+                    "/p", "--expert_id", "5"])
+    assert a.expert_id == 5 and a.seed == 43 and a.pretrained_model_name_or_path == "stabilityai/stable-diffusion-2-1"

@@ -1,0 +1,64 @@
+"""CPU: the oracle against the committed golden vectors, which were produced by the REFERENCE's own importable pieces
+(oracle/validate_against_reference.py: pdm.utils.metric_utils.compute_snr, the vendored CompVis ResBlock /
+SpatialTransformer / timestep_embedding / beta schedule)."""
+import os
+
+import numpy as np
+import torch
+
+from pdm_ref import arch, step, unet, weights
+from pdm_ref.config import UNetConfig
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_twins.npz"))
+
+
+def T(name):
+    return torch.from_numpy(GOLD[name])
+
+
+def test_snr_and_min_snr_weights_match_reference():
+    ac = step.alphas_cumprod()
+    t = T("snr_t")
+    assert torch.allclose(step.compute_snr(ac, t), T("snr_ref"), rtol=1e-6, atol=0)
+    assert torch.allclose(step.min_snr_weights(ac, t), T("minsnr_w_ref"), rtol=1e-6, atol=0)
+    # known answers recorded in SURVEY.md 8c
+    snr = step.compute_snr(ac, torch.tensor([0, 499, 999]))
+    assert torch.allclose(snr, torch.tensor([1175.4, 0.38441, 0.0046819]), rtol=2e-4)
+
+
+def test_schedule_and_timestep_embedding_match_ldm_twins():
+    assert torch.allclose(step.alphas_cumprod().double(), T("alphas_cumprod_f64"), atol=1e-5)
+    assert torch.allclose(unet.timestep_embedding(T("temb_t"), 320), T("temb_ref"), atol=1e-6)
+
+
+def _sd(prefix):
+    return {k[len(prefix):]: T(k) for k in GOLD.files if k.startswith(prefix)}
+
+
+def test_resblock_matches_ldm_resblock():
+    for cin, cout in ((64, 64), (96, 64)):
+        tag = f"resblock_{cin}_{cout}"
+        y = unet.resblock(_sd(tag + "_w_"), "r", T(tag + "_x"), T(tag + "_emb"), 32, 32)
+        assert torch.allclose(y, T(tag + "_y"), atol=2e-5, rtol=1e-5)
+
+
+def test_transformer_matches_ldm_spatial_transformer():
+    y = unet.transformer2d(_sd("st_w_"), "a", T("st_x"), T("st_ctx"), 2, 2, 64, 32)
+    assert torch.allclose(y, T("st_y"), atol=2e-5, rtol=1e-5)
+
+
+def test_arch_vector_layout_and_param_count():
+    cfg = UNetConfig.sd21()
+    s = arch.structure(cfg)
+    assert sum(map(sum, s["width"])) == 1606 and sum(map(sum, s["depth"])) == 14
+    assert arch.hard_concrete(torch.tensor([[0.2, 0.5, 0.9]])).tolist() == [[0.0, 1.0, 1.0]]
+    # SD-2.1 U-Net parameter count, without materialising the weights: shapes only
+    n = 0
+    tiny = UNetConfig.tiny()
+    sd = weights.init_dense_state_dict(tiny, 0)
+    psd, info = weights.prune_state_dict(sd, tiny, arch.random_arch_vector(tiny, 0.5, 0, drop_depth=(0, 13)))
+    assert info["down_blocks.0.resnets.1"]["dropped"] and info["up_blocks.3.attentions.2"]["dropped"]
+    assert not any(k.startswith("down_blocks.0.resnets.1.") for k in psd)
+    lat, t, ehs = torch.randn(1, 4, 8, 8), torch.tensor([3]), torch.randn(1, 5, 64)
+    out = unet.unet_forward(psd, tiny, info, lat, t, ehs)
+    assert out.shape == lat.shape and torch.isfinite(out).all()

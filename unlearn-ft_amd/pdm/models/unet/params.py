@@ -224,7 +224,7 @@ class ParamStore:
 
     # ---- state dict interchange (diffusers names, pruned shapes)
     @torch.no_grad()
-    def load_state_dict(self, sd, strict=True):
+    def load_state_dict(self, sd, strict=True, refresh=True):
         seen = set()
         for e in self.entries:
             packed = torch.zeros(e.shape)
@@ -251,7 +251,8 @@ class ParamStore:
             extra = set(sd) - seen
             if extra:
                 raise KeyError(f"unexpected keys in state dict: {sorted(extra)[:5]} ...")
-        self.refresh()
+        if refresh:
+            self.refresh()
 
     @torch.no_grad()
     def state_dict(self, arena=None):

@@ -187,6 +187,19 @@ def get_random_arch_vector(target_ratio, structure, generator=None):
     return torch.cat(parts, dim=1)
 
 
+def force_width_non_zero(arch_vector, structure):
+    """transform_arch_vector(..., force_width_non_zero=True) (hypernet.py:112-118): a gate with no kept unit gets its
+    first unit raised by 0.5 so no layer ends up with zero width."""
+    av = arch_vector.clone()
+    start = 0
+    for sub in structure["width"]:
+        for w in sub:
+            if not (av[0, start:start + w] >= 0.5).any():
+                av[0, start] += 0.5
+            start += w
+    return av
+
+
 def hard_concrete(x):
     """pdm/utils/estimation_utils.py:67-75 (forward value): 1 where x >= 0.5 else 0."""
     return (x >= 0.5).to(torch.float32)
@@ -264,7 +277,8 @@ def arch_vector_for_budget(cfg: UNetConfig, budget, hw=64, ctx_len=77, seed=0, t
     best = None
     for _ in range(24):
         mid = 0.5 * (lo + hi)
-        av = get_random_arch_vector(mid, gate_structure(cfg), torch.Generator().manual_seed(seed))
+        av = force_width_non_zero(get_random_arch_vector(mid, gate_structure(cfg), torch.Generator().manual_seed(seed)),
+                                  gate_structure(cfg))
         ratio = plan_macs(cfg, apply_arch_vector(cfg, av), hw, ctx_len)[0] / dense
         if best is None or abs(ratio - budget) < abs(best[1] - budget):
             best = (av, ratio, mid)
