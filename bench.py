@@ -200,9 +200,18 @@ def main():
                  (2, 1): "igemm<colk,colk> (linear wgrad)", (2, 2): "igemm<colk,colk_conv> (conv3x3 wgrad)"}
         ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
         peak = 2500.0 if a.dtype == "bf16" else 157.3
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_igemm.json")
+        if os.path.exists(tfile) and not a.tiny:
+            # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # same command (tools/summarize_pmc.py; gfx950 2x FETCH_SIZE correction applied); counters cannot be read live
+            short = {(0, 0): "rowk,rowk", (1, 0): "conv,rowk", (2, 1): "colk,colk", (2, 2): "colk,colk_conv"}
+            rec = json.load(open(tfile)).get(f"{dom[0][0]} igemm<{short[(dom[0][1], dom[0][2])]}>")
+            traffic = rec and round(rec["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": f"{dom[0][0]} {names[(dom[0][1], dom[0][2])]}",
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": None, "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
+                "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_igemm.json)",
+                "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
                 "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),
                 "all_gemm_kinds": {f"{kd[0]} {names[(kd[1], kd[2])]}": {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
                                                                          "ms": round(v[1], 2), "launches": v[2]}
