@@ -93,17 +93,19 @@ int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float*
 int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, double* ws,
                        int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps, int silu, int dtype,
                        pdmk_stream stream);
-/* dx = d(loss)/dx given dy; dgamma/dbeta (fp32 [G*gs]) are ACCUMULATED (+=).  ws: B*G*2 doubles. */
+/* dx = d(loss)/dx given dy; dgamma/dbeta (fp32 [G*gs]) are ACCUMULATED (+=).  ws: B*G*2 doubles.  part_ws: float
+ * scratch for the two-stage per-channel reduction, part_ws_elems >= 2048 * 2 * G*gs is always enough (-1 if too small). */
 int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
-                       const float* stats, float* dgamma, float* dbeta, double* ws, int B, int HW, int C, int ldx,
-                       int lddy, int lddx, int G, int gs, int silu, int accumulate_dx, int dtype, pdmk_stream stream);
+                       const float* stats, float* dgamma, float* dbeta, double* ws, float* part_ws,
+                       int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G, int gs,
+                       int silu, int accumulate_dx, int dtype, pdmk_stream stream);
 
 /* LayerNorm over the last dim (eps 1e-5; diffusers BasicTransformerBlock.norm1/2/3). stats [M,2]. */
 int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M, int C,
                        int ldx, int ldy, float eps, int dtype, pdmk_stream stream);
 int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
-                       float* dgamma, float* dbeta, int M, int C, int ldx, int lddy, int lddx, int accumulate_dx,
-                       int dtype, pdmk_stream stream);
+                       float* dgamma, float* dbeta, float* part_ws, int64_t part_ws_elems /* >= (M/16 + 1) * 2 * C */,
+                       int M, int C, int ldx, int lddy, int lddx, int accumulate_dx, int dtype, pdmk_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, head dim 64, no mask, no dropout (F.scaled_dot_product_attention at

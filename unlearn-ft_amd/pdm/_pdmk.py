@@ -47,9 +47,9 @@ _SIGS = {
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
-    "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
-    "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
     "pdmk_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
                        i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
@@ -161,10 +161,24 @@ def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps,
                                  eps, int(silu), dt(x), _st()), "pdmk_groupnorm_fwd")
 
 
+_PART_WS = {}
+
+
+def part_ws(device, elems):
+    """Per-device fp32 scratch for the two-stage per-channel gradient reductions (reused launch after launch: all users
+    are ordered on one stream)."""
+    buf = _PART_WS.get(device)
+    if buf is None or buf.numel() < elems:
+        buf = torch.empty(max(elems, 1 << 22), device=device, dtype=torch.float32)
+        _PART_WS[device] = buf
+    return buf
+
+
 def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc):
+    pw = part_ws(x.device, 2048 * 2 * G * gs)
     _chk(_lib.pdmk_groupnorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), _p(ws),
-                                 B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), dt(x), _st()),
-         "pdmk_groupnorm_bwd")
+                                 _p(pw), pw.numel(), B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), dt(x),
+                                 _st()), "pdmk_groupnorm_bwd")
 
 
 def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
@@ -173,8 +187,9 @@ def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
 
 
 def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc):
-    _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), M, Cc, ldx, lddy,
-                                 lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
+    pw = part_ws(x.device, (M // 16 + 1) * 2 * Cc)
+    _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), _p(pw),
+                                 pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
 
 
 def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale):
