@@ -21,17 +21,21 @@ namespace {
 #define PDMK_GEMM_PF2 0      // 1: two K-tiles in flight in registers (measured SLOWER on MI355X: +60-120 VGPRs), 0: one
 #endif
 constexpr int BM = 128, BN = 128, NTHREADS = 256;
-constexpr int OPERAND_BYTES = 18432;      // 128 x 144 B  ==  64(32) k-rows x 144 elements
-
-template <typename T> struct TileCfg {
+// Two K-step geometries are instantiated and chosen per launch (measured on MI355X): KCH = 16-byte chunks per tile row.
+//   KCH=8: K-step 64 bf16, 72 KiB LDS -> 2 blocks/CU, 32 MFMAs per barrier: best when the grid fits 512 slots;
+//   KCH=4: K-step 32 bf16, 48 KiB LDS -> 3 blocks/CU: best when the grid is larger (e.g. 768 tiles run in ONE round).
+template <typename T, int KCHUNKS> struct TileCfg {
+    static constexpr int NLD = KCHUNKS / 2;             // 16-byte loads per thread and operand (two threads per row)
+    static constexpr int ROW_BYTES = KCHUNKS == 8 ? 144 : 96;               // padded LDS row of a rowk tile
+    static constexpr int OPERAND_BYTES = 128 * ROW_BYTES;                   // >= (KCHUNKS*CH) k-rows x 144 elements
     static constexpr int CH = Mma<T>::CH;               // elements per 16-byte chunk
-    static constexpr int BK = 8 * CH;                   // 64 bf16 / 32 fp32: 8 chunks per tile row
-    static constexpr int RS_ROWK = BK + CH;             // 144-byte rows
+    static constexpr int BK = KCHUNKS * CH;             // 64 bf16 / 32 fp32 at 8 chunks per tile row
+    static constexpr int RS_ROWK = ROW_BYTES / (int)sizeof(T);
     static constexpr int RS_COLK = 128 + 16;
-    static constexpr int G4 = 4 * CH;                   // elements one thread loads per operand (64 bytes)
+    static constexpr int G4 = NLD * CH;                 // elements one thread loads per operand (64 / 32 bytes)
     static constexpr int GPR = 128 / G4;                // thread groups per 128-wide row (colk layouts): 4 / 8
-    static_assert(BM * RS_ROWK * sizeof(T) == OPERAND_BYTES, "rowk tile bytes");
-    static_assert(BK * RS_COLK * sizeof(T) == OPERAND_BYTES, "colk tile bytes");
+    static_assert(BM * RS_ROWK * sizeof(T) <= OPERAND_BYTES, "rowk tile bytes");
+    static_assert(BK * RS_COLK * sizeof(T) <= OPERAND_BYTES, "colk tile bytes");
     static_assert(NTHREADS / GPR == BK && 2 * G4 == BK, "one tile row per thread");
 };
 
@@ -57,12 +61,12 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any operand (operands are < 2 GiB): buffer loads return 0
 
-template <typename T, int AMODE, int BMODE, int CMODE>
+template <typename T, int AMODE, int BMODE, int CMODE, int KCH>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
                                                          unsigned b_bytes) {
-    typedef TileCfg<T> TC;
+    typedef TileCfg<T, KCH> TC;
     typedef Mma<T> MM;
-    constexpr int CH = TC::CH, BK = TC::BK;
+    constexpr int CH = TC::CH, BK = TC::BK, NLD = TC::NLD, OPERAND_BYTES = TC::OPERAND_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[PDMK_GEMM_NBUF][2][OPERAND_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -116,9 +120,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         b_ci = col - b_tap * cg.ci;
     }
 
-    u32x4 ra[4], rb[4];
+    u32x4 ra[NLD], rb[NLD];
 #if PDMK_GEMM_PF2
-    u32x4 ra2[4], rb2[4];     // second register set: two tiles in flight
+    u32x4 ra2[NLD], rb2[NLD];     // second register set: two tiles in flight
 #endif
     // fused bias gradient (wgrad only): the blocks of the first n-tile also sum their A = dY tiles over the reduction
     // dim; every tile passes through store_tiles exactly once, which is where the registers are summed.
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
 
     auto load4 = [&](u32x4* r, const decltype(rsrcA)& rs, unsigned voff) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u * j), 0, 0);
+        for (int j = 0; j < NLD; ++j) r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(voff + 16u * j), 0, 0);
     };
 
     auto load_tiles = [&](int kt, u32x4* ra, u32x4* rb) {
@@ -183,13 +187,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         T* ad = (AMODE == PDMK_A_COLK) ? As + ckr * TC::RS_COLK + cq : As + lr * TC::RS_ROWK + lq;
         T* bd = (BMODE != PDMK_B_ROWK) ? Bs + ckr * TC::RS_COLK + cq : Bs + lr * TC::RS_ROWK + lq;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NLD; ++j) {
             *reinterpret_cast<u32x4*>(ad + j * CH) = ra[j];
             *reinterpret_cast<u32x4*>(bd + j * CH) = rb[j];
         }
         if (do_colsum) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NLD; ++j) {
                 const T* v = reinterpret_cast<const T*>(&ra[j]);
 #pragma unroll
                 for (int e = 0; e < CH; ++e) csum[j * CH + e] += to_f32(v[e]);
@@ -378,9 +382,17 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
     const long b_bytes = g.b_mode == PDMK_B_ROWK ? ((long)(g.N - 1) * g.ldb + g.K) * esz
                        : g.b_mode == PDMK_B_COLK ? ((long)(g.K - 1) * g.ldb + g.N) * esz : conv_bytes;
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -1;     // 32-bit buffer offsets
-#define PDMK_GO(AM, BMD, CM)                                                                               \
-    hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM>), grid, block, 0, st, g, lg_wo, lg_howo, (unsigned)a_bytes, \
-                       (unsigned)b_bytes)
+    // more blocks than the 2-per-CU geometry can hold at once -> the 3-per-CU geometry runs them in fewer rounds
+    const bool small_k = (long)grid.x * grid.y > 512;
+#define PDMK_GO(AM, BMD, CM)                                                                                        \
+    do {                                                                                                            \
+        if (small_k)                                                                                                \
+            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 4>), grid, block, 0, st, g, lg_wo, lg_howo,            \
+                               (unsigned)a_bytes, (unsigned)b_bytes);                                               \
+        else                                                                                                        \
+            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 8>), grid, block, 0, st, g, lg_wo, lg_howo,            \
+                               (unsigned)a_bytes, (unsigned)b_bytes);                                               \
+    } while (0)
     if (g.a_mode == PDMK_A_ROWK && g.b_mode == PDMK_B_ROWK) PDMK_GO(PDMK_A_ROWK, PDMK_B_ROWK, 0);
     else if (g.a_mode == PDMK_A_CONV && g.b_mode == PDMK_B_ROWK) {
         switch (g.conv_mode) {
@@ -410,7 +422,7 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     const pdmk_gemm_args& g = *a;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
     const int ch = g.dtype == PDMK_BF16 ? 8 : 4;     // elements per 16 bytes
-    const int g4 = 4 * ch;                             // a thread moves 64 contiguous bytes: 32 bf16 / 16 fp32
+    const int g4 = 4 * ch;                             // a thread moves up to 64 contiguous bytes: 32 bf16 / 16 fp32
     if (g.dtype != PDMK_BF16 && g.dtype != PDMK_F32) return -2;
     if (g.a_mode != PDMK_A_COLK && (g.K % g4)) return -1;   // reduction-major operands predicate every k-row
     if (((uintptr_t)g.A | (uintptr_t)g.B) & 15) return -1;

@@ -138,7 +138,9 @@ def splitk_plan(M, N, K, kstep=64):
     """Split factor for a forward/dgrad GEMM whose output grid cannot fill the chip (1 = do not split)."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nk = K // kstep
-    if tiles > 192 or nk < 64 or (N & 3):      # only deep-K, few-tile GEMMs (3x3 convs at 8x8 / 16x16 latents)
+    # only deep-K, few-tile GEMMs (3x3 convs at 8x8 / 16x16 latents); measured: splitting 160-tile K=5120..5760 GEMMs
+    # loses to the fp32 workspace round trip, 160 tiles at K=11520 and anything below ~100 tiles wins
+    if tiles > 160 or nk < 64 or (tiles > 96 and nk < 160) or (N & 3):
         return 1
     return max(1, min(nk // 16, -(-512 // tiles), 16))
 
