@@ -277,82 +277,118 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
+    // ---------------------------------------------------------------- epilogue (staged through LDS)
+    // The accumulators go through an fp32 LDS image [64][132] in two passes (upper / lower 64 rows of the tile) so that
+    // global traffic is row-contiguous: 16-byte stores / residual loads per lane on the plain path, and 256 contiguous
+    // bytes per wave-instruction on the split-K float-atomic path (scattered 4-byte atomics run ~10x slower).
     const bool first = blockIdx.y == 0;
-    const bool vec = ((g.N & 3) == 0) && ((g.ldc & 3) == 0) && (g.R == nullptr || (g.ldr & 3) == 0);
     const bool atomic = gridDim.y > 1;
+    const bool f32out = g.out_f32 || sizeof(T) == 4;
+    const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
+    constexpr int SROW = 132;
+    float* stage = reinterpret_cast<float*>(smem);
+    static_assert(64 * SROW * 4 <= PDMK_GEMM_NBUF * 2 * OPERAND_BYTES, "staging image must fit the tile buffers");
     float* Cf = reinterpret_cast<float*>(g.C);
     T* Ct = reinterpret_cast<T*>(g.C);
     const T* Rp = reinterpret_cast<const T*>(g.R);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= g.M) continue;
-        const float* rv = (g.rowvec && first) ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if (wm == pass) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nb = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (nb >= g.N) continue;
-            float v[4];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * g.alpha;
-            const int nv = min(4, g.N - nb);
-            if (first) {
-                if (vec) {
-                    if (g.bias) {
-                        const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    if (rv) {
-                        const float4 bb = *reinterpret_cast<const float4*>(rv + nb);
-                        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-                    }
-                    if (Rp) {
-                        if (sizeof(T) == 2) {
-                            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(Rp + (long)m * g.ldr + nb);
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i][j];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
-                        } else {
-                            const float4 rr = *reinterpret_cast<const float4*>(Rp + (long)m * g.ldr + nb);
-                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                    *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * SROW + wn * 64 + j * 16 + (lane >> 4) * 4) = v;
+                }
+        }
+        __syncthreads();
+        if (atomic) {
+            for (int rr = 0; rr < 16; ++rr) {
+                const int lrow = wave * 16 + rr, m = m0 + pass * 64 + lrow;
+                if (m >= g.M) break;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int n = n0 + h * 64 + lane;
+                    if (n < g.N) {
+                        float v = stage[lrow * SROW + h * 64 + lane];
+                        if (first) {
+                            if (g.bias) v += g.bias[n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (Rp) v += to_f32(Rp[(long)m * g.ldr + n]);
                         }
-                    }
-                } else {
-                    for (int r = 0; r < nv; ++r) {
-                        if (g.bias) v[r] += g.bias[nb + r];
-                        if (rv) v[r] += rv[nb + r];
-                        if (Rp) v[r] += to_f32(Rp[(long)m * g.ldr + nb + r]);
+                        unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
                     }
                 }
             }
-            const long off = (long)m * g.ldc + nb;
-            if (g.out_f32 || sizeof(T) == 4) {
-                if (atomic) {
-                    for (int r = 0; r < nv; ++r) unsafeAtomicAdd(Cf + off + r, v[r]);
-                } else if (vec) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (g.accumulate) {
-                        const float4 c = *reinterpret_cast<const float4*>(Cf + off);
-                        o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w;
-                    }
-                    *reinterpret_cast<float4*>(Cf + off) = o;
-                } else {
-                    for (int r = 0; r < nv; ++r) Cf[off + r] = v[r] + (g.accumulate ? Cf[off + r] : 0.f);
-                }
-            } else {
-                if (vec) {
-                    if (g.accumulate) {
-                        const bf16x4 c = *reinterpret_cast<const bf16x4*>(Ct + off);
+        } else {
+            const int lrow = tid >> 2, seg = (tid & 3) * 32;
+            const int m = m0 + pass * 64 + lrow;
+            if (m < g.M) {
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
-                    }
-                    bf16x4 o;
+                for (int c8 = 0; c8 < 4; ++c8) {
+                    const int n = n0 + seg + c8 * 8;
+                    if (n >= g.N) break;
+                    float v[8];
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lrow * SROW + seg + c8 * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lrow * SROW + seg + c8 * 8 + 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                    *reinterpret_cast<bf16x4*>(Ct + off) = o;
-                } else {
-                    for (int r = 0; r < nv; ++r)
-                        Ct[off + r] = from_f32<T>(v[r] + (g.accumulate ? to_f32(Ct[off + r]) : 0.f));
+                    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+                    const long off = (long)m * g.ldc + n;
+                    if (vec8) {
+                        if (g.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (rv) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(rv + n), b1 = *reinterpret_cast<const float4*>(rv + n + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (Rp) {
+                            if (sizeof(T) == 2) {
+                                const bf16x8 rr = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
+                            } else {
+                                const float* rp = reinterpret_cast<const float*>(Rp) + (long)m * g.ldr + n;
+                                const float4 b0 = *reinterpret_cast<const float4*>(rp), b1 = *reinterpret_cast<const float4*>(rp + 4);
+                                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                            }
+                        }
+                        if (f32out) {
+                            float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                            if (g.accumulate) {
+                                const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
+                                o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+                            }
+                            *reinterpret_cast<float4*>(Cf + off) = o0;
+                            *reinterpret_cast<float4*>(Cf + off + 4) = o1;
+                        } else {
+                            if (g.accumulate) {
+                                const bf16x8 c = *reinterpret_cast<const bf16x8*>(Ct + off);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += (float)c[r];
+                            }
+                            bf16x8 o;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                            *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                        }
+                    } else {
+                        const int nv = min(8, g.N - n);
+                        for (int r = 0; r < nv; ++r) {
+                            float x = v[r];
+                            if (g.bias) x += g.bias[n + r];
+                            if (rv) x += rv[n + r];
+                            if (Rp) x += to_f32(Rp[(long)m * g.ldr + n + r]);
+                            if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
+                            else Ct[off + r] = from_f32<T>(x + (g.accumulate ? to_f32(Ct[off + r]) : 0.f));
+                        }
+                    }
                 }
             }
         }

@@ -66,7 +66,7 @@ class UNetEngine:
     def _splitk(m_out, n_out, red, step):
         tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
         nk = max(1, red // step)
-        return max(1, min(512 // max(tiles, 1), nk // 32, 64))   # >= 32 K-steps per split (measured sweet spot)
+        return max(1, min(512 // max(tiles, 1), nk // 16, 64))   # >= 16 K-steps per split (measured sweet spot)
 
     # ------------------------------------------------------------------ ops
     def linear(self, x, key, bias=None, residual=None, out_f32=False):
