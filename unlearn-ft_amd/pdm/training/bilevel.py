@@ -317,17 +317,17 @@ class GraphedBilevel:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main):
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             st.main_step(self.lat, self.noise, self.t, self.ehs)
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             st.opt.launch(st._gscale)
         if bilevel:
             self.g_upper = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_upper):
+            with torch.cuda.graph(self.g_upper, capture_error_mode="thread_local"):
                 st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
             self.g_uopt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_uopt):
+            with torch.cuda.graph(self.g_uopt, capture_error_mode="thread_local"):
                 st.upper_opt.launch(st._gscale)
         torch.cuda.synchronize()
         store.master.copy_(snap[0]); store.grad.copy_(snap[1])
