@@ -3,10 +3,17 @@
 // The N x N score matrix is never materialised: per 64-row query block the kernel walks key blocks with an online
 // (base-2) softmax; fp32 statistics; LSE saved for the backward.  Q/K/V/O are addressed with explicit batch/row strides
 // so the fused QKV projection output is consumed in place (no head transposes in HBM).
-// Backward = delta pre-pass + a dK/dV kernel (one workgroup per 64 keys sweeps the queries) + a dQ kernel (one
-// workgroup per 64 queries sweeps the keys): no atomics, bitwise reproducible.
-// K / Q / dO tiles are held ONCE in LDS in memory order and read both k-contiguous (ds_read_b128) and transposed
-// (ds_read_b64_tr_b16) depending on which product consumes them.
+//
+// Register-resident probabilities: every product is oriented so that the score tile comes out of the MFMA with the
+// index that the NEXT product sums over in the accumulator REGISTERS (and the other index on the lanes).  The
+// accumulators are then converted in place and fed back as the B operand (Mma<T>::acc_frag); the matching A operand is
+// read transposed from the K / V / Q / dO tile that already sits in LDS in memory order (Mma<T>::load_colk_accs =
+// ds_read_b64_tr_b16 with the same k permutation).  P, dS never touch LDS; softmax statistics are per-lane scalars.
+//   forward : S^T = K Q^T  (key in regs, query on lanes)   O^T += V^T P^T
+//   dK/dV   : S   = Q K^T  (query in regs, key on lanes)   dV^T += dO^T P,  dK^T += Q^T dS   (no atomics)
+//   dQ      : S^T = K Q^T                                  dQ^T += K^T dS^T
+// K/V (resp. Q/dO) tiles are double buffered in LDS; the next tile's buffer loads (hardware zero-fill past the sequence
+// end) are issued before the current tile's MFMAs: one barrier per tile.
 #include "common.h"
 
 namespace {
@@ -14,6 +21,8 @@ namespace {
 constexpr int NT = 256;
 constexpr int D = 64;
 constexpr float LOG2E = 1.4426950408889634f;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+constexpr unsigned OOB = 0x80000000u;
 
 template <typename T> struct ACfg;
 template <> struct ACfg<bf16> {
@@ -23,17 +32,35 @@ template <> struct ACfg<float> {
     static constexpr int CH = 4, RS = 68, KVB = 32;
 };
 
-// global [rows, 64] (row stride ld) -> LDS [ROWS][RS]; rows >= nvalid are zero-filled
-template <typename T, int ROWS>
-__device__ __forceinline__ void load_tile(T* lds, const T* g, long ld, int row0, int nrows, int tid) {
-    constexpr int CH = ACfg<T>::CH, RS = ACfg<T>::RS, CPR = D / CH;
-    for (int c = tid; c < ROWS * CPR; c += NT) {
-        const int r = c / CPR, dc = (c % CPR) * CH;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(g + (long)(row0 + r) * ld + dc);
-        *reinterpret_cast<uint4*>(lds + r * RS + dc) = v;
+// A [ROWS][64] tile of a strided [N][..] matrix: buffer loads into registers (rows past the end read as zero), LDS
+// image [ROWS][RS].  NR = 16-byte chunks per thread.
+template <typename T, int ROWS> struct TileIO {
+    static constexpr int CH = ACfg<T>::CH, RS = ACfg<T>::RS, CPR = D / CH, NR = ROWS * CPR / NT;
+    static_assert(ROWS * CPR % NT == 0, "tile chunks must divide the block");
+    template <typename RS_T>
+    static __device__ __forceinline__ void load(u32x4* r, const RS_T& rsrc, int ld, int row0, int nrows, int tid) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = tid + i * NT, row = row0 + c / CPR, dc = (c % CPR) * CH;
+            const unsigned off = row < nrows ? ((unsigned)row * (unsigned)ld + (unsigned)dc) * (unsigned)sizeof(T) : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0);
+        }
     }
+    static __device__ __forceinline__ void store(T* lds, const u32x4* r, int tid) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = tid + i * NT;
+            *reinterpret_cast<u32x4*>(lds + (c / CPR) * RS + (c % CPR) * CH) = r[i];
+        }
+    }
+};
+
+template <typename T> __device__ __forceinline__ auto make_rsrc(const T* p, long nrows, int ld) {
+    // upper bound of the bytes addressable from p within this (batch, head) slice
+    const long bytes = ((nrows - 1) * (long)ld + D) * (long)sizeof(T);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p), (short)0, (int)bytes, 0x00020000);
 }
+
 // wave-private LDS [16][RS] (cols 0..63) -> global rows, 16-byte stores; rows >= nrows skipped
 template <typename T>
 __device__ __forceinline__ void store_tile16(const T* lds, T* g, long ld, int row0, int nrows, int lane) {
@@ -44,6 +71,26 @@ __device__ __forceinline__ void store_tile16(const T* lds, T* g, long ld, int ro
             *reinterpret_cast<uint4*>(g + (long)(row0 + r) * ld + dc) = *reinterpret_cast<const uint4*>(lds + r * RS + dc);
     }
 }
+// accumulators X^T[d][c] (d = dt*16 + 4g + r in registers, c = lane&15) -> wave-private LDS [c][d] image
+template <typename T>
+__device__ __forceinline__ void stage_t(T* lds, const f32x4* acc, float scale, int lane) {
+    constexpr int RS = ACfg<T>::RS;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            lds[(lane & 15) * RS + dt * 16 + (lane >> 4) * 4 + r] = from_f32<T>(acc[dt][r] * scale);
+}
+
+template <typename MM, int S, int NS> struct AccLoop {     // compile-time loop over the MFMA steps of one tile pair
+    template <typename F> static __device__ __forceinline__ void run(F&& f) {
+        f(std::integral_constant<int, S>{});
+        AccLoop<MM, S + 1, NS>::run(f);
+    }
+};
+template <typename MM, int NS> struct AccLoop<MM, NS, NS> {
+    template <typename F> static __device__ __forceinline__ void run(F&&) {}
+};
 
 // ================================================================================================ forward
 template <typename T>
@@ -54,96 +101,98 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
                                                       int o_ld, float scale2) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, KVB = AC::KVB, NJ = KVB / 16, RSP = KVB + (sizeof(T) == 2 ? 8 : 4);
+    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16;
+    typedef TileIO<T, 64> QIO;
+    typedef TileIO<T, KVB> KIO;
     __shared__ __attribute__((aligned(16))) T Qs[64 * RS];
-    __shared__ __attribute__((aligned(16))) T Ks[KVB * RS];
-    __shared__ __attribute__((aligned(16))) T Vs[KVB * RS];
-    __shared__ __attribute__((aligned(16))) T Ps[4 * 16 * RSP];
+    __shared__ __attribute__((aligned(16))) T Ks[2][KVB * RS];
+    __shared__ __attribute__((aligned(16))) T Vs[2][KVB * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const T* qg = q + b * q_bs + h * D;
-    const T* kg = k + b * k_bs + h * D;
-    const T* vg = v + b * v_bs + h * D;
+    const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
+    const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
+    const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
 
-    load_tile<T, 64>(Qs, qg, q_ld, q0, Nq, tid);
+    u32x4 rq_[QIO::NR], rk_[KIO::NR], rv_[KIO::NR];
+    QIO::load(rq_, rq, q_ld, q0, Nq, tid);
+    KIO::load(rk_, rk, k_ld, 0, Nk, tid);
+    KIO::load(rv_, rv, v_ld, 0, Nk, tid);
+    QIO::store(Qs, rq_, tid);
+    KIO::store(Ks[0], rk_, tid);
+    KIO::store(Vs[0], rv_, tid);
     __syncthreads();
-    typename MM::frag qf[D / MM::KS];
+    typename MM::frag qf[D / MM::KS];      // B operand: B[k = d][col = query]
 #pragma unroll
     for (int kk = 0; kk < D / MM::KS; ++kk) qf[kk] = MM::load_rowk(Qs, RS, wave * 16, kk * MM::KS, lane);
 
-    f32x4 oacc[4];
-    float mrow[4], lrow[4];
+    f32x4 ot[4];                            // O^T[d = dt*16 + 4g + r][query = lane&15]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; mrow[i] = -INFINITY; lrow[i] = 0.f; }
-    T* Pw = Ps + wave * 16 * RSP;
+    for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;   // per query column (l: this lane group's share)
 
+    int cur = 0;
     for (int kb = 0; kb < Nk; kb += KVB) {
-        __syncthreads();   // previous block's K/V/P reads done
-        load_tile<T, KVB>(Ks, kg, k_ld, kb, Nk, tid);
-        load_tile<T, KVB>(Vs, vg, v_ld, kb, Nk, tid);
-        __syncthreads();
-        f32x4 s[NJ];
+        const bool more = kb + KVB < Nk;
+        if (more) {
+            KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
+            KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
+        }
+        f32x4 st[NKT];                      // S^T[key = 16t + 4g + r][query]
+        float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NKT; ++t) {
+            st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < D / MM::KS; ++kk)
-                s[j] = MM::mma(qf[kk], MM::load_rowk(Ks, RS, j * 16, kk * MM::KS, lane), s[j]);
-        }
-        // lane: rows q=(lane>>4)*4+r, cols key = kb + 16j + (lane&15)
-        float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const bool valid = kb + j * 16 + (lane & 15) < Nk;
+                st[t] = MM::mma(MM::load_rowk(Ks[cur], RS, t * 16, kk * MM::KS, lane), qf[kk], st[t]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[j][r] = valid ? s[j][r] * scale2 : -INFINITY;
-                mx[r] = fmaxf(mx[r], s[j][r]);
+                const bool valid = kb + t * 16 + (lane >> 4) * 4 + r < Nk;
+                st[t][r] = valid ? st[t][r] * scale2 : -INFINITY;
+                mx = fmaxf(mx, st[t][r]);
             }
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - mn);
+        m_run = mn;
+        l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
-            const float mn = fmaxf(mrow[r], mx[r]);
-            const float alpha = exp2f(mrow[r] - mn);
-            mrow[r] = mn;
-            lrow[r] *= alpha;
+            for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt][r] *= alpha;
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(s[j][r] - mrow[r]);
-                lrow[r] += p;
-                Pw[((lane >> 4) * 4 + r) * RSP + j * 16 + (lane & 15)] = from_f32<T>(p);
+                st[t][r] = exp2f(st[t][r] - mn);
+                l_run += st[t][r];
             }
+#pragma unroll
+        for (int pr = 0; pr < NKT / 2; ++pr) {
+            AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                const typename MM::frag pf = MM::template acc_frag<S>(st[2 * pr], st[2 * pr + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    ot[dt] = MM::mma(MM::template load_colk_accs<S>(Vs[cur], RS, pr * 32, dt * 16, lane), pf, ot[dt]);
+            });
+        }
+        if (more) {
+            KIO::store(Ks[cur ^ 1], rk_, tid);
+            KIO::store(Vs[cur ^ 1], rv_, tid);
+        }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < KVB / MM::KS; ++kk) {
-            const typename MM::frag pf = MM::load_rowk(Pw, RSP, 0, kk * MM::KS, lane);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                oacc[dt] = MM::mma(pf, MM::load_colk(Vs, RS, kk * MM::KS, dt * 16, lane), oacc[dt]);
-        }
+        cur ^= 1;
     }
-    // finalize: l over the 16 lanes of a row
-    T* Ow = Qs + wave * 16 * RS;   // this wave's own Q rows, free since qf was hoisted
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float l = lrow[r];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) l += __shfl_xor(l, off, 64);
-        const float inv = 1.0f / l;
-        const int qr = (lane >> 4) * 4 + r;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Ow[qr * RS + dt * 16 + (lane & 15)] = from_f32<T>(oacc[dt][r] * inv);
-        const int qi = q0 + wave * 16 + qr;
-        if ((lane & 15) == 0 && qi < Nq) lse[((long)b * H + h) * Nq + qi] = mrow[r] + log2f(l);
-    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    T* Ow = Qs + wave * 16 * RS;           // this wave's own Q rows, free since qf was hoisted
+    stage_t<T>(Ow, ot, 1.0f / l_run, lane);
+    const int qi = q0 + wave * 16 + (lane & 15);
+    if (lane < 16 && qi < Nq) lse[((long)b * H + h) * Nq + qi] = m_run + log2f(l_run);
     __syncthreads();
     store_tile16<T>(Ow, o + b * o_bs + h * D, o_ld, q0 + wave * 16, Nq, lane);
 }
@@ -173,7 +222,7 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
     }
 }
 
-// one workgroup = 64 keys of one (b,h); wave w owns keys 16w..16w+15; sweeps query blocks of QB rows.
+// one workgroup = 64 keys of one (b,h); wave w owns keys 16w..16w+15 (on the lanes); sweeps query blocks of QB rows.
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, const T* __restrict__ d_o,
@@ -185,98 +234,105 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
                                                           int dv_ld, float scale, float scale2) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, QB = AC::KVB, NJ = QB / 16, RSP = QB + (sizeof(T) == 2 ? 8 : 4);
-    // region U: K,V staging (hoisted into registers), then reused for the wave-private P^T / dS^T tiles
-    __shared__ __attribute__((aligned(16))) T U[2 * 64 * RS];
-    __shared__ __attribute__((aligned(16))) T Qs[QB * RS];
-    __shared__ __attribute__((aligned(16))) T Os[QB * RS];
-    __shared__ float Ls[QB], Ds[QB];
-    static_assert(2 * 4 * 16 * RSP <= 2 * 64 * RS, "P/dS tiles must fit the K/V staging region");
+    constexpr int RS = AC::RS, QB = AC::KVB, NQT = QB / 16;
+    typedef TileIO<T, 64> KIO;
+    typedef TileIO<T, QB> QIO;
+    __shared__ __attribute__((aligned(16))) T Ks[64 * RS];     // K, V staging; reused for the dK / dV output staging
+    __shared__ __attribute__((aligned(16))) T Vs[64 * RS];
+    __shared__ __attribute__((aligned(16))) T Qs[2][QB * RS];
+    __shared__ __attribute__((aligned(16))) T Os[2][QB * RS];
+    __shared__ float Ls[2][QB], Ds[2][QB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const T* qg = q + b * q_bs + h * D;
-    const T* og = d_o + b * o_bs + h * D;
+    const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
+    const auto ro = make_rsrc(d_o + b * o_bs + h * D, Nq, o_ld);
+    const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
+    const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
+    const float* lse_bh = lse + ((long)b * H + h) * Nq;
+    const float* del_bh = delta + ((long)b * H + h) * Nq;
 
-    load_tile<T, 64>(U, k + b * k_bs + h * D, k_ld, k0, Nk, tid);
-    load_tile<T, 64>(U + 64 * RS, v + b * v_bs + h * D, v_ld, k0, Nk, tid);
+    u32x4 rk_[KIO::NR], rv_[KIO::NR], rq_[QIO::NR], ro_[QIO::NR];
+    float rl = INFINITY, rd = 0.f;
+    KIO::load(rk_, rk, k_ld, k0, Nk, tid);
+    KIO::load(rv_, rv, v_ld, k0, Nk, tid);
+    QIO::load(rq_, rq, q_ld, 0, Nq, tid);
+    QIO::load(ro_, ro, o_ld, 0, Nq, tid);
+    if (tid < QB && tid < Nq) { rl = lse_bh[tid]; rd = del_bh[tid]; }
+    KIO::store(Ks, rk_, tid);
+    KIO::store(Vs, rv_, tid);
+    QIO::store(Qs[0], rq_, tid);
+    QIO::store(Os[0], ro_, tid);
+    if (tid < QB) { Ls[0][tid] = rl; Ds[0][tid] = rd; }
     __syncthreads();
-    typename MM::frag kf[D / MM::KS], vf[D / MM::KS];
+    typename MM::frag kf[D / MM::KS], vf[D / MM::KS];      // B operands: B[k = d][col = key]
 #pragma unroll
     for (int kk = 0; kk < D / MM::KS; ++kk) {
-        kf[kk] = MM::load_rowk(U, RS, wave * 16, kk * MM::KS, lane);
-        vf[kk] = MM::load_rowk(U + 64 * RS, RS, wave * 16, kk * MM::KS, lane);
+        kf[kk] = MM::load_rowk(Ks, RS, wave * 16, kk * MM::KS, lane);
+        vf[kk] = MM::load_rowk(Vs, RS, wave * 16, kk * MM::KS, lane);
     }
-    T* Pw = U + wave * 16 * RSP;
-    T* Sw = U + 4 * 16 * RSP + wave * 16 * RSP;
-
-    f32x4 dka[4], dva[4];
+    f32x4 dkt[4], dvt[4];                  // dK^T / dV^T [d = dt*16 + 4g + r][key = lane&15]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { dka[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dva[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    // lane: rows key=(lane>>4)*4+r (this wave's 16 keys), cols q = qb + 16j + (lane&15)
-    bool kvalid[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) kvalid[r] = k0 + wave * 16 + (lane >> 4) * 4 + r < Nk;
+    for (int i = 0; i < 4; ++i) { dkt[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const bool kvalid = k0 + wave * 16 + (lane & 15) < Nk;
 
+    int cur = 0;
     for (int qb = 0; qb < Nq; qb += QB) {
-        __syncthreads();
-        load_tile<T, QB>(Qs, qg, q_ld, qb, Nq, tid);
-        load_tile<T, QB>(Os, og, o_ld, qb, Nq, tid);
-        if (tid < QB) {
-            const bool ok = qb + tid < Nq;
-            Ls[tid] = ok ? lse[((long)b * H + h) * Nq + qb + tid] : INFINITY;
-            Ds[tid] = ok ? delta[((long)b * H + h) * Nq + qb + tid] : 0.f;
+        const bool more = qb + QB < Nq;
+        if (more) {
+            QIO::load(rq_, rq, q_ld, qb + QB, Nq, tid);
+            QIO::load(ro_, ro, o_ld, qb + QB, Nq, tid);
+            rl = INFINITY; rd = 0.f;
+            if (tid < QB && qb + QB + tid < Nq) { rl = lse_bh[qb + QB + tid]; rd = del_bh[qb + QB + tid]; }
         }
-        __syncthreads();
+        f32x4 p[NQT], ds[NQT];             // P / dS [query = 16t + 4g + r][key]
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NQT; ++t) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < D / MM::KS; ++kk) {
-                st = MM::mma(kf[kk], MM::load_rowk(Qs, RS, j * 16, kk * MM::KS, lane), st);
-                dp = MM::mma(vf[kk], MM::load_rowk(Os, RS, j * 16, kk * MM::KS, lane), dp);
+                s = MM::mma(MM::load_rowk(Qs[cur], RS, t * 16, kk * MM::KS, lane), kf[kk], s);
+                dp = MM::mma(MM::load_rowk(Os[cur], RS, t * 16, kk * MM::KS, lane), vf[kk], dp);
             }
-            const float l2 = Ls[j * 16 + (lane & 15)], dl = Ds[j * 16 + (lane & 15)];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = kvalid[r] ? exp2f(st[r] * scale2 - l2) : 0.f;
-                const float ds = p * (dp[r] - dl);
-                const int off = ((lane >> 4) * 4 + r) * RSP + j * 16 + (lane & 15);
-                Pw[off] = from_f32<T>(p);
-                Sw[off] = from_f32<T>(ds);
+                const int qq = t * 16 + (lane >> 4) * 4 + r;
+                const float pv = kvalid ? exp2f(s[r] * scale2 - Ls[cur][qq]) : 0.f;
+                p[t][r] = pv;
+                ds[t][r] = pv * (dp[r] - Ds[cur][qq]);
             }
+        }
+#pragma unroll
+        for (int pr = 0; pr < NQT / 2; ++pr) {
+            AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                const typename MM::frag pf = MM::template acc_frag<S>(p[2 * pr], p[2 * pr + 1]);
+                const typename MM::frag sf = MM::template acc_frag<S>(ds[2 * pr], ds[2 * pr + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dvt[dt] = MM::mma(MM::template load_colk_accs<S>(Os[cur], RS, pr * 32, dt * 16, lane), pf, dvt[dt]);
+                    dkt[dt] = MM::mma(MM::template load_colk_accs<S>(Qs[cur], RS, pr * 32, dt * 16, lane), sf, dkt[dt]);
+                }
+            });
+        }
+        if (more) {
+            QIO::store(Qs[cur ^ 1], rq_, tid);
+            QIO::store(Os[cur ^ 1], ro_, tid);
+            if (tid < QB) { Ls[cur ^ 1][tid] = rl; Ds[cur ^ 1][tid] = rd; }
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < QB / MM::KS; ++kk) {
-            const typename MM::frag pf = MM::load_rowk(Pw, RSP, 0, kk * MM::KS, lane);
-            const typename MM::frag sf = MM::load_rowk(Sw, RSP, 0, kk * MM::KS, lane);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dva[dt] = MM::mma(pf, MM::load_colk(Os, RS, kk * MM::KS, dt * 16, lane), dva[dt]);
-                dka[dt] = MM::mma(sf, MM::load_colk(Qs, RS, kk * MM::KS, dt * 16, lane), dka[dt]);
-            }
-        }
+        cur ^= 1;
     }
-    __syncthreads();
-    // stage through this wave's rows of Qs / Os for 16-byte stores (QB*RS >= 4*16*RS only when QB==64; use U instead)
-    T* Kw = U + wave * 16 * RS;
-    T* Vw = U + 64 * RS + wave * 16 * RS;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int kr = (lane >> 4) * 4 + r;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            Kw[kr * RS + dt * 16 + (lane & 15)] = from_f32<T>(dka[dt][r] * scale);
-            Vw[kr * RS + dt * 16 + (lane & 15)] = from_f32<T>(dva[dt][r]);
-        }
-    }
+    T* Kw = Ks + wave * 16 * RS;           // K/V staging is free (fragments hoisted, all reads behind barriers)
+    T* Vw = Vs + wave * 16 * RS;
+    stage_t<T>(Kw, dkt, scale, lane);
+    stage_t<T>(Vw, dvt, 1.0f, lane);
     __syncthreads();
     store_tile16<T>(Kw, dk + b * dk_bs + h * D, dk_ld, k0 + wave * 16, Nk, lane);
     store_tile16<T>(Vw, dv + b * dv_bs + h * D, dv_ld, k0 + wave * 16, Nk, lane);
 }
 
-// one workgroup = 64 queries of one (b,h); wave w owns 16 rows; sweeps key blocks.
+// one workgroup = 64 queries of one (b,h); wave w owns 16 queries (on the lanes); sweeps key blocks.
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, const T* __restrict__ d_o,
@@ -287,88 +343,101 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
                                                          int dq_ld, float scale, float scale2) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, KVB = AC::KVB, NJ = KVB / 16, RSP = KVB + (sizeof(T) == 2 ? 8 : 4);
-    __shared__ __attribute__((aligned(16))) T U[2 * 64 * RS];   // Q, dO staging -> dS tiles -> dQ staging
-    __shared__ __attribute__((aligned(16))) T Ks[KVB * RS];
-    __shared__ __attribute__((aligned(16))) T Vs[KVB * RS];
+    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16;
+    typedef TileIO<T, 64> QIO;
+    typedef TileIO<T, KVB> KIO;
+    __shared__ __attribute__((aligned(16))) T Qs[64 * RS];      // Q staging, then dQ output staging
+    __shared__ __attribute__((aligned(16))) T Os[64 * RS];
+    __shared__ __attribute__((aligned(16))) T Ks[2][KVB * RS];
+    __shared__ __attribute__((aligned(16))) T Vs[2][KVB * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const T* kg = k + b * k_bs + h * D;
-    const T* vg = v + b * v_bs + h * D;
+    const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
+    const auto ro = make_rsrc(d_o + b * o_bs + h * D, Nq, o_ld);
+    const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
+    const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
 
-    load_tile<T, 64>(U, q + b * q_bs + h * D, q_ld, q0, Nq, tid);
-    load_tile<T, 64>(U + 64 * RS, d_o + b * o_bs + h * D, o_ld, q0, Nq, tid);
+    u32x4 rq_[QIO::NR], ro_[QIO::NR], rk_[KIO::NR], rv_[KIO::NR];
+    QIO::load(rq_, rq, q_ld, q0, Nq, tid);
+    QIO::load(ro_, ro, o_ld, q0, Nq, tid);
+    KIO::load(rk_, rk, k_ld, 0, Nk, tid);
+    KIO::load(rv_, rv, v_ld, 0, Nk, tid);
+    QIO::store(Qs, rq_, tid);
+    QIO::store(Os, ro_, tid);
+    KIO::store(Ks[0], rk_, tid);
+    KIO::store(Vs[0], rv_, tid);
     __syncthreads();
-    typename MM::frag qf[D / MM::KS], of[D / MM::KS];
+    typename MM::frag qf[D / MM::KS], of[D / MM::KS];       // B operands: B[k = d][col = query]
 #pragma unroll
     for (int kk = 0; kk < D / MM::KS; ++kk) {
-        qf[kk] = MM::load_rowk(U, RS, wave * 16, kk * MM::KS, lane);
-        of[kk] = MM::load_rowk(U + 64 * RS, RS, wave * 16, kk * MM::KS, lane);
+        qf[kk] = MM::load_rowk(Qs, RS, wave * 16, kk * MM::KS, lane);
+        of[kk] = MM::load_rowk(Os, RS, wave * 16, kk * MM::KS, lane);
     }
-    float l2[4], dl[4];
+    const int qi = q0 + wave * 16 + (lane & 15);
+    const float l2 = qi < Nq ? lse[((long)b * H + h) * Nq + qi] : INFINITY;
+    const float dl = qi < Nq ? delta[((long)b * H + h) * Nq + qi] : 0.f;
+    f32x4 dqt[4];                           // dQ^T[d][query]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = q0 + wave * 16 + (lane >> 4) * 4 + r;
-        l2[r] = qi < Nq ? lse[((long)b * H + h) * Nq + qi] : INFINITY;
-        dl[r] = qi < Nq ? delta[((long)b * H + h) * Nq + qi] : 0.f;
-    }
-    T* Sw = U + wave * 16 * RSP;
-    f32x4 dqa[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dqa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) dqt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    int cur = 0;
     for (int kb = 0; kb < Nk; kb += KVB) {
-        __syncthreads();
-        load_tile<T, KVB>(Ks, kg, k_ld, kb, Nk, tid);
-        load_tile<T, KVB>(Vs, vg, v_ld, kb, Nk, tid);
-        __syncthreads();
+        const bool more = kb + KVB < Nk;
+        if (more) {
+            KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
+            KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
+        }
+        f32x4 dst[NKT];                     // dS^T[key = 16t + 4g + r][query]
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int t = 0; t < NKT; ++t) {
             f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < D / MM::KS; ++kk) {
-                s = MM::mma(qf[kk], MM::load_rowk(Ks, RS, j * 16, kk * MM::KS, lane), s);
-                dp = MM::mma(of[kk], MM::load_rowk(Vs, RS, j * 16, kk * MM::KS, lane), dp);
+                s = MM::mma(MM::load_rowk(Ks[cur], RS, t * 16, kk * MM::KS, lane), qf[kk], s);
+                dp = MM::mma(MM::load_rowk(Vs[cur], RS, t * 16, kk * MM::KS, lane), of[kk], dp);
             }
-            const bool valid = kb + j * 16 + (lane & 15) < Nk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = valid ? exp2f(s[r] * scale2 - l2[r]) : 0.f;
-                Sw[((lane >> 4) * 4 + r) * RSP + j * 16 + (lane & 15)] = from_f32<T>(p * (dp[r] - dl[r]));
+                const bool valid = kb + t * 16 + (lane >> 4) * 4 + r < Nk;
+                const float pv = valid ? exp2f(s[r] * scale2 - l2) : 0.f;
+                dst[t][r] = pv * (dp[r] - dl);
             }
         }
-        __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < KVB / MM::KS; ++kk) {
-            const typename MM::frag sf = MM::load_rowk(Sw, RSP, 0, kk * MM::KS, lane);
+        for (int pr = 0; pr < NKT / 2; ++pr) {
+            AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                const typename MM::frag sf = MM::template acc_frag<S>(dst[2 * pr], dst[2 * pr + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                dqa[dt] = MM::mma(sf, MM::load_colk(Ks, RS, kk * MM::KS, dt * 16, lane), dqa[dt]);
+                for (int dt = 0; dt < 4; ++dt)
+                    dqt[dt] = MM::mma(MM::template load_colk_accs<S>(Ks[cur], RS, pr * 32, dt * 16, lane), sf, dqt[dt]);
+            });
         }
+        if (more) {
+            KIO::store(Ks[cur ^ 1], rk_, tid);
+            KIO::store(Vs[cur ^ 1], rv_, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
-    __syncthreads();
-    T* Qw = U + 64 * RS + wave * 16 * RS;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qr = (lane >> 4) * 4 + r;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Qw[qr * RS + dt * 16 + (lane & 15)] = from_f32<T>(dqa[dt][r] * scale);
-    }
+    T* Qw = Qs + wave * 16 * RS;
+    stage_t<T>(Qw, dqt, scale, lane);
     __syncthreads();
     store_tile16<T>(Qw, dq + b * dq_bs + h * D, dq_ld, q0 + wave * 16, Nq, lane);
 }
 
-template <typename T> bool aligned_ok(const void* p, long bs, int ld) {
+template <typename T> bool aligned_ok(const void* p, long bs, int ld, long nrows) {
     constexpr int CH = ACfg<T>::CH;
-    return (((uintptr_t)p) & 15) == 0 && (bs % CH) == 0 && (ld % CH) == 0;
+    return (((uintptr_t)p) & 15) == 0 && (bs % CH) == 0 && (ld % CH) == 0 &&
+           ((nrows - 1) * (long)ld + D) * (long)sizeof(T) < (1L << 31);
 }
 
 template <typename T>
 int attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, long q_bs,
              int q_ld, long k_bs, int k_ld, long v_bs, int v_ld, long o_bs, int o_ld, float scale, hipStream_t st) {
-    if (!aligned_ok<T>(q, q_bs, q_ld) || !aligned_ok<T>(k, k_bs, k_ld) || !aligned_ok<T>(v, v_bs, v_ld) ||
-        !aligned_ok<T>(o, o_bs, o_ld))
+    if (!aligned_ok<T>(q, q_bs, q_ld, Nq) || !aligned_ok<T>(k, k_bs, k_ld, Nk) || !aligned_ok<T>(v, v_bs, v_ld, Nk) ||
+        !aligned_ok<T>(o, o_bs, o_ld, Nq))
         return -1;
     dim3 grid((Nq + 63) / 64, H, B);
     hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(NT), 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, H,
@@ -382,9 +451,9 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
              float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, long q_bs, int q_ld, long k_bs,
              int k_ld, long v_bs, int v_ld, long o_bs, int o_ld, long dq_bs, int dq_ld, long dk_bs, int dk_ld,
              long dv_bs, int dv_ld, float scale, hipStream_t st) {
-    if (!aligned_ok<T>(q, q_bs, q_ld) || !aligned_ok<T>(k, k_bs, k_ld) || !aligned_ok<T>(v, v_bs, v_ld) ||
-        !aligned_ok<T>(o, o_bs, o_ld) || !aligned_ok<T>(d_o, o_bs, o_ld) || !aligned_ok<T>(dq, dq_bs, dq_ld) ||
-        !aligned_ok<T>(dk, dk_bs, dk_ld) || !aligned_ok<T>(dv, dv_bs, dv_ld))
+    if (!aligned_ok<T>(q, q_bs, q_ld, Nq) || !aligned_ok<T>(k, k_bs, k_ld, Nk) || !aligned_ok<T>(v, v_bs, v_ld, Nk) ||
+        !aligned_ok<T>(o, o_bs, o_ld, Nq) || !aligned_ok<T>(d_o, o_bs, o_ld, Nq) || !aligned_ok<T>(dq, dq_bs, dq_ld, Nq) ||
+        !aligned_ok<T>(dk, dk_bs, dk_ld, Nk) || !aligned_ok<T>(dv, dv_bs, dv_ld, Nk))
         return -1;
     const long total = (long)B * H * Nq;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((int)min(4096L, (total + NT - 1) / NT)), dim3(NT), 0, st,

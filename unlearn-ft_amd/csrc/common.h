@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/pdmk.h"
 
@@ -68,6 +69,32 @@ template <> struct Mma<bf16> {
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     }
+    // Same as load_colk but with the reduction index permuted so that it matches an ACCUMULATOR tile pair used as the
+    // other operand: an MFMA result X (16 x 16, lane l holds rows 4(l>>4)+r of column l&15) can feed the next MFMA as
+    // its B operand (sum over X's rows) without touching LDS if k-slot (g = l>>4, j) means row (j<4 ? 4g+j : 16+4g+j-4)
+    // of the 32-row pair (two stacked 16-row tiles).  This loads the matching A/B fragment from a [k][col] LDS image.
+    static __device__ __forceinline__ frag load_colk_acc(const bf16* lds, int rs, int k0, int col0, int lane) {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const bf16* a0 = lds + (k0 + 4 * g + q) * rs + col0 + 4 * p;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * rs));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    // two stacked accumulator tiles (rows 0..15 and 16..31 of the pair) -> operand fragment in the slot order above
+    static __device__ __forceinline__ frag pack_acc(f32x4 t0, f32x4 t1) {
+        bf16x8 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = (bf16)t0[r]; v[4 + r] = (bf16)t1[r]; }
+        return v;
+    }
+    static constexpr int ACC_STEPS = 1;     // MFMAs that consume one 32-row pair of accumulator tiles
+    template <int S> static __device__ __forceinline__ frag acc_frag(f32x4 t0, f32x4 t1) { return pack_acc(t0, t1); }
+    template <int S>
+    static __device__ __forceinline__ frag load_colk_accs(const bf16* lds, int rs, int k0, int col0, int lane) {
+        return load_colk_acc(lds, rs, k0, col0, lane);
+    }
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
@@ -82,6 +109,14 @@ template <> struct Mma<float> {
     }
     static __device__ __forceinline__ frag load_colk(const float* lds, int rs, int k0, int col0, int lane) {
         return lds[(k0 + (lane >> 4)) * rs + col0 + (lane & 15)];
+    }
+    // accumulator tiles as operands (see Mma<bf16>): with k = 4 per instruction, step S of a 32-row pair takes register
+    // S&3 of tile S>>2; k-slot g = lane>>4 is then row 16*(S>>2) + 4g + (S&3) of the pair.
+    static constexpr int ACC_STEPS = 8;
+    template <int S> static __device__ __forceinline__ frag acc_frag(f32x4 t0, f32x4 t1) { return S < 4 ? t0[S & 3] : t1[S & 3]; }
+    template <int S>
+    static __device__ __forceinline__ frag load_colk_accs(const float* lds, int rs, int k0, int col0, int lane) {
+        return lds[(k0 + 16 * (S >> 2) + 4 * (lane >> 4) + (S & 3)) * rs + col0 + (lane & 15)];
     }
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
