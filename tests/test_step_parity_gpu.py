@@ -159,3 +159,40 @@ def test_upper_step_matches_oracle(dev, dn):
         big = [n for n, p in P.items() if p.numel() >= 4096]
         cos = min(torch.nn.functional.cosine_similarity(grads[n].flatten(), P[n].grad.flatten(), dim=0).item() for n in big)
         assert cos > 0.98, cos
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_full_size_sd21_main_step_matches_oracle(dev, dn):
+    """BASELINE.json configs[0]: the REAL SD-2.1 topology (865.9 M-parameter dense teacher, MAC-budget-0.55 student),
+    B=1, 64x64 latent, 77x1024 text states: main-step losses of the HIP engine vs the CPU oracle (fp32 engine 1e-3,
+    bf16 engine 3e-2 relative - north_star: "loss curves matching the CPU reference to 1e-3" for the fp32 path)."""
+    from pdm_ref import step as ostep, weights as oweights
+    from pdm_ref.config import UNetConfig as OCfg
+    from pdm.models.unet.spec import UNetConfig, arch_vector_for_budget
+    from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+    from pdm.training.bilevel import BilevelStepper
+    dtype = torch.float32 if dn == "f32" else torch.bfloat16
+    ocfg, cfg = OCfg.sd21(), UNetConfig.sd21()
+    av, ratio, _ = arch_vector_for_budget(cfg, 0.55)
+    teacher = UNet2DConditionModelPruned(cfg, None, "cuda:0", dtype, train=False, seed=0)
+    dense = teacher.state_dict()                      # the oracle gets exactly the weights the engine holds
+    student = UNet2DConditionModelPruned(cfg, av, "cuda:0", dtype, train=True, init=False)
+    student.load_dense_or_pruned(dense)
+    psd, info = oweights.prune_state_dict(dense, ocfg, av)
+    mine = student.state_dict()
+    assert set(mine) == set(psd) and all(mine[k_].shape == psd[k_].shape for k_ in psd)
+    g = torch.Generator().manual_seed(43)
+    lat, noise = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 4, 64, 64, generator=g)
+    t, ehs = torch.tensor([431]), torch.randn(1, 77, 1024, generator=g)
+    with torch.no_grad():
+        loss, diff, dist_, block, _ = ostep.main_step_loss((psd, info), (dense, oweights.dense_info(ocfg)), ocfg,
+                                                           ostep.alphas_cumprod(), lat, noise, t, ehs)
+    st = BilevelStepper(student, teacher)
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=(dn == "bf16")))
+    tol = 1e-3 if dn == "f32" else 3e-2
+    for name, got, ref in (("diff", d, diff.item()), ("dist", s, dist_.item()), ("block", b, block.item()),
+                           ("total", tot, loss.item())):
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref, ratio)
+    if dn == "bf16":        # the backward ran: gradients are finite and the packed padding carries none
+        gsum = float(student.store.grad.double().abs().sum())
+        assert math.isfinite(gsum) and gsum > 0
