@@ -20,12 +20,17 @@ namespace {
 #ifndef PDMK_GEMM_PF2
 #define PDMK_GEMM_PF2 0      // 1: two K-tiles in flight in registers (measured SLOWER on MI355X: +60-120 VGPRs), 0: one
 #endif
-constexpr int BM = 128, BN = 128, NTHREADS = 256;
-// Two K-step geometries are instantiated and chosen per launch (measured on MI355X): KCH = 16-byte chunks per tile row.
-//   KCH=8: K-step 64 bf16, 72 KiB LDS -> 2 blocks/CU, 32 MFMAs per barrier: best when the grid fits 512 slots;
-//   KCH=4: K-step 32 bf16, 48 KiB LDS -> 3 blocks/CU: best when the grid is larger (e.g. 768 tiles run in ONE round).
-template <typename T, int KCHUNKS> struct TileCfg {
-    static constexpr int NLD = KCHUNKS / 2;             // 16-byte loads per thread and operand (two threads per row)
+constexpr int BM = 128, BN = 128;
+// Three geometries are instantiated and chosen per launch (measured on MI355X, tools/gemm_bench.py):
+//   KCH = 16-byte chunks per tile row:  8 -> K-step 64 bf16, 72 KiB LDS (2 blocks/CU);  4 -> K-step 32, 48 KiB (3/CU)
+//   NW  = waves per workgroup:          8 -> 32x64 per wave (more waves per SIMD hide LDS/barrier latency: default)
+//                                       4 -> 64x64 per wave (fewer LDS fragment reads per MFMA: wins on deep-K GEMMs
+//                                            with more than 512 tiles, e.g. the 320->320 conv at 64x64)
+template <typename T, int KCHUNKS, int NW> struct TileCfg {
+    static constexpr int NTHREADS = 64 * NW;
+    static constexpr int IM = 8 / NW * 2;               // 16-row MFMA tiles per wave (4 or 2)
+    static constexpr int TPR = NTHREADS / 128;          // threads per tile row (2 or 4)
+    static constexpr int NLD = KCHUNKS / TPR;           // 16-byte loads per thread and operand
     static constexpr int ROW_BYTES = KCHUNKS == 8 ? 144 : 96;               // padded LDS row of a rowk tile
     static constexpr int OPERAND_BYTES = 128 * ROW_BYTES;                   // >= (KCHUNKS*CH) k-rows x 144 elements
     static constexpr int CH = Mma<T>::CH;               // elements per 16-byte chunk
@@ -33,10 +38,10 @@ template <typename T, int KCHUNKS> struct TileCfg {
     static constexpr int RS_ROWK = ROW_BYTES / (int)sizeof(T);
     static constexpr int RS_COLK = 128 + 16;
     static constexpr int G4 = NLD * CH;                 // elements one thread loads per operand (64 / 32 bytes)
-    static constexpr int GPR = 128 / G4;                // thread groups per 128-wide row (colk layouts): 4 / 8
+    static constexpr int GPR = 128 / G4;                // thread groups per 128-wide row (colk layouts)
     static_assert(BM * RS_ROWK * sizeof(T) <= OPERAND_BYTES, "rowk tile bytes");
     static_assert(BK * RS_COLK * sizeof(T) <= OPERAND_BYTES, "colk tile bytes");
-    static_assert(NTHREADS / GPR == BK && 2 * G4 == BK, "one tile row per thread");
+    static_assert(NTHREADS / GPR == BK && TPR * G4 == BK && NLD >= 1, "one tile row per thread");
 };
 
 struct ConvGeom {
@@ -61,12 +66,13 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned OOB = 0x80000000u;    // byte offset beyond any operand (operands are < 2 GiB): buffer loads return 0
 
-template <typename T, int AMODE, int BMODE, int CMODE, int KCH>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
+template <typename T, int AMODE, int BMODE, int CMODE, int KCH, int NW>
+__global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
                                                          unsigned b_bytes) {
-    typedef TileCfg<T, KCH> TC;
+    typedef TileCfg<T, KCH, NW> TC;
     typedef Mma<T> MM;
     constexpr int CH = TC::CH, BK = TC::BK, NLD = TC::NLD, OPERAND_BYTES = TC::OPERAND_BYTES;
+    constexpr int NTHREADS = TC::NTHREADS, IM = TC::IM;
     __shared__ __attribute__((aligned(16))) unsigned char smem[PDMK_GEMM_NBUF][2][OPERAND_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
     const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld, lg_wo, lg_howo};
 
     // ---------------------------------------------------------------- per-thread loader state (one row per operand)
-    const int lr = tid >> 1, lq = (tid & 1) * G4;              // rowk-type: tile row, element offset inside the k-tile
+    const int lr = tid / TC::TPR, lq = (tid % TC::TPR) * G4;   // rowk-type: tile row, element offset inside the k-tile
     const int ckr = tid / TC::GPR, cq = (tid % TC::GPR) * G4;  // colk-type: k-row inside the tile, column offset
 
     unsigned a_base = OOB;                 // rowk: byte offset of the row start
@@ -201,9 +207,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[IM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -212,17 +218,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
         const T* Bs = reinterpret_cast<const T*>(smem[cur][1]);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += MM::KS) {
-            typename MM::frag af[4], bf[4];
+            typename MM::frag af[IM], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[i] = (AMODE == PDMK_A_COLK) ? MM::load_colk(As, TC::RS_COLK, kk, wm * 64 + i * 16, lane)
-                                               : MM::load_rowk(As, TC::RS_ROWK, wm * 64 + i * 16, kk, lane);
+            for (int i = 0; i < IM; ++i)
+                af[i] = (AMODE == PDMK_A_COLK) ? MM::load_colk(As, TC::RS_COLK, kk, wm * (16 * IM) + i * 16, lane)
+                                               : MM::load_rowk(As, TC::RS_ROWK, wm * (16 * IM) + i * 16, kk, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 bf[j] = (BMODE != PDMK_B_ROWK) ? MM::load_colk(Bs, TC::RS_COLK, kk, wn * 64 + j * 16, lane)
                                                : MM::load_rowk(Bs, TC::RS_ROWK, wn * 64 + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
         }
@@ -294,21 +300,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
-        if (wm == pass) {
+        if ((wm * IM) / 4 == pass) {
+            const int lrb = (wm * 16 * IM) % 64;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[i][j];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
-                    *reinterpret_cast<f32x4*>(stage + (i * 16 + (lane & 15)) * SROW + wn * 64 + j * 16 + (lane >> 4) * 4) = v;
+                    *reinterpret_cast<f32x4*>(stage + (lrb + i * 16 + (lane & 15)) * SROW + wn * 64 + j * 16 + (lane >> 4) * 4) = v;
                 }
         }
         __syncthreads();
         if (atomic) {
-            for (int rr = 0; rr < 16; ++rr) {
-                const int lrow = wave * 16 + rr, m = m0 + pass * 64 + lrow;
+            for (int rr = 0; rr < 64 / NW; ++rr) {
+                const int lrow = wave * (64 / NW) + rr, m = m0 + pass * 64 + lrow;
                 if (m >= g.M) break;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -325,12 +332,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(pdmk_gemm_args g, int l
                 }
             }
         } else {
-            const int lrow = tid >> 2, seg = (tid & 3) * 32;
+            constexpr int TPS = NTHREADS / 64, SEG = 128 / TPS;     // threads per staged row, columns per thread
+            const int lrow = tid / TPS, seg = (tid % TPS) * SEG;
             const int m = m0 + pass * 64 + lrow;
             if (m < g.M) {
                 const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
 #pragma unroll
-                for (int c8 = 0; c8 < 4; ++c8) {
+                for (int c8 = 0; c8 < SEG / 8; ++c8) {
                     const int n = n0 + seg + c8 * 8;
                     if (n >= g.N) break;
                     float v[8];
@@ -404,7 +412,7 @@ inline int ilog2_exact(int v) {
 
 template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
     const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    dim3 grid(mt * nt, g.splitk > 1 ? g.splitk : 1), block(NTHREADS);
+    dim3 grid(mt * nt, g.splitk > 1 ? g.splitk : 1);
     int lg_wo = -1, lg_howo = -1;
     if (g.b_mode == PDMK_B_COLK_CONV) {
         lg_wo = ilog2_exact(g.conv_wo);
@@ -419,14 +427,20 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
                        : g.b_mode == PDMK_B_COLK ? ((long)(g.K - 1) * g.ldb + g.N) * esz : conv_bytes;
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -1;     // 32-bit buffer offsets
     // more blocks than the 2-per-CU geometry can hold at once -> the 3-per-CU geometry runs them in fewer rounds
-    const bool small_k = (long)grid.x * grid.y > 512;
+    const bool many = (long)grid.x * grid.y > 512;            // more blocks than the 2-per-CU geometry holds at once
+    // (the 4-wave 64x64-per-wave geometry wins isolated deep-K micro-benchmarks by up to 17 % but loses inside the real
+    // step, where operands are not L2-warm: not dispatched)
+    const bool deep4 = false;
 #define PDMK_GO(AM, BMD, CM)                                                                                        \
     do {                                                                                                            \
-        if (small_k)                                                                                                \
-            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 4>), grid, block, 0, st, g, lg_wo, lg_howo,            \
+        if (deep4)                                                                                                  \
+            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 4, 4>), grid, dim3(256), 0, st, g, lg_wo, lg_howo,     \
+                               (unsigned)a_bytes, (unsigned)b_bytes);                                               \
+        else if (many)                                                                                              \
+            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 4, 8>), grid, dim3(512), 0, st, g, lg_wo, lg_howo,     \
                                (unsigned)a_bytes, (unsigned)b_bytes);                                               \
         else                                                                                                        \
-            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 8>), grid, block, 0, st, g, lg_wo, lg_howo,            \
+            hipLaunchKernelGGL((igemm_kernel<T, AM, BMD, CM, 8, 8>), grid, dim3(512), 0, st, g, lg_wo, lg_howo,     \
                                (unsigned)a_bytes, (unsigned)b_bytes);                                               \
     } while (0)
     if (g.a_mode == PDMK_A_ROWK && g.b_mode == PDMK_B_ROWK) PDMK_GO(PDMK_A_ROWK, PDMK_B_ROWK, 0);
