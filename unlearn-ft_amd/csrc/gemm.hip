@@ -12,6 +12,8 @@
 // transposed by ds_read_b64_tr_b16 on the way into the MFMA fragments.  The MFMA is issued with operands swapped
 // (D = B.A^T) so a lane ends up with 4 consecutive n of one output row: 8/16-byte epilogue loads and stores.
 // Blocks are remapped so that the n-tiles of one m-tile run back to back on one XCD (shared activation panel in L2).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -467,6 +469,17 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
 
 }  // namespace
 
+int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes);   // gemm_dma.hip
+
+static int dma_mode() {        // PDMK_GEMM_DMA=0 forces the register-staged kernel everywhere (A/B testing)
+    static int m = -1;
+    if (m < 0) {
+        const char* e = getenv("PDMK_GEMM_DMA");
+        m = e ? atoi(e) : 1;
+    }
+    return m;
+}
+
 extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (!a || !a->A || !a->B || !a->C) return -1;
     const pdmk_gemm_args& g = *a;
@@ -495,6 +508,18 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.splitk > 1 && !(g.out_f32 || g.dtype == PDMK_F32)) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // LDS-DMA ring kernel (gemm_dma.hip) for the large-grid forward / dgrad GEMMs: measured +7..18 % there; the deep-K
+    // small-grid layers (16x16 / 8x8 latents) keep the K-step-64 register-staged kernel (fewer barriers per MFMA)
+    const long nblocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.splitk > 1 ? g.splitk : 1);
+    if (dma_mode() && nblocks >= 384 && g.dtype == PDMK_BF16 && g.b_mode == PDMK_B_ROWK && g.a_mode != PDMK_A_COLK) {
+        const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * 2;
+        const long ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2 : conv_bytes;
+        const long bb = ((long)(g.N - 1) * g.ldb + g.K) * 2;
+        if (ab < (1L << 31) && bb < (1L << 31)) {
+            const int rc = pdmk_gemm_dma_launch(g, st, ab, bb);
+            if (rc <= 0) return rc;
+        }
+    }
     return g.dtype == PDMK_BF16 ? launch<bf16>(g, st) : launch<float>(g, st);
 }
 

@@ -1,0 +1,278 @@
+// Implicit GEMM, LDS-DMA variant (bf16, A = activation rows or 3x3 gather, B = weights [N][K]): the forward / dgrad
+// work-horse.  Same math and epilogue as gemm.hip; what changes is how tiles reach the matrix cores:
+//   * operands go global -> LDS directly (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, and
+//     out-of-range lanes (conv halo, M/N tails) are zero-filled into LDS by the buffer unit;
+//   * a 4-slot ring of 128x32 (A) + 128x32 (B) bf16 tiles (16 KiB per slot, 64 KiB per workgroup -> 2 workgroups/CU,
+//     16 waves/CU) keeps THREE K-steps in flight behind a counted s_waitcnt vmcnt(N): HBM / L2 latency is covered by
+//     prefetch distance instead of by occupancy; one raw s_barrier per K-step;
+//   * LDS image is lane-linear (a DMA wave-instruction writes 1 KiB = 16 rows x 64 B); bank conflicts of the
+//     ds_read_b128 fragment reads are removed by XOR-swizzling the 16-byte chunk index with (row>>2)&3 on the SOURCE
+//     side (per-lane global address) and on the read side.
+#include "common.h"
+
+namespace pdmk_dma {
+
+constexpr int BM = 128, BN = 128, BK = 32, NT = 512, STAGES = 4;
+constexpr int TILE_BYTES = 128 * BK * 2;               // 8 KiB per operand per slot
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct ConvGeom {
+    int hi, wi, ci, ho, wo, ld;
+};
+
+template <int CMODE>
+__device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, int ox, int tap) {
+    const int ky = (tap * 11) >> 5;
+    const int kx = tap - 3 * ky;
+    int vy, vx;
+    if (CMODE == 1) { vy = 2 * oy + ky - 1; vx = 2 * ox + kx - 1; }
+    else            { vy = oy + ky - 1;     vx = ox + kx - 1; }
+    const int hv = (CMODE >= 2) ? 2 * g.hi : g.hi, wv = (CMODE >= 2) ? 2 * g.wi : g.wi;
+    bool ok = (unsigned)vy < (unsigned)hv && (unsigned)vx < (unsigned)wv;
+    if (CMODE == 3) ok = ok && (((vy | vx) & 1) == 0);
+    const int iy = (CMODE >= 2) ? (vy >> 1) : vy, ix = (CMODE >= 2) ? (vx >> 1) : vx;
+    return ok ? (b * g.hi + iy) * g.wi + ix : -1;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt();
+template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+
+template <bool CONV, int CMODE>
+__global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    typedef Mma<bf16> MM;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * 2 * TILE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves, 32 x 64 outputs each
+    const int ntn = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int nk_total = g.K / BK;
+    const int per = (nk_total + gridDim.y - 1) / gridDim.y;
+    const int kt0 = blockIdx.y * per;
+    const int kt1 = min(nk_total, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
+    const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld};
+
+    // ---- loader state: thread -> (tile row = tid>>2, physical 16-byte chunk = tid&3); logical chunk = phys ^ swizzle
+    const int lrow = tid >> 2;
+    const int lchunk = ((tid & 3) ^ ((lrow >> 2) & 3)) * 8;          // element offset inside the 32-wide k-tile
+    unsigned a_base = OOB, b_base = OOB;
+    int a_b = -1, a_oy = 0, a_ox = 0;
+    {
+        const int m = m0 + lrow;
+        if (m < g.M) {
+            if (CONV) {
+                const int hw = cg.ho * cg.wo;
+                a_b = m / hw;
+                const int rem = m - a_b * hw;
+                a_oy = rem / cg.wo;
+                a_ox = rem - a_oy * cg.wo;
+            } else {
+                a_base = (unsigned)m * (unsigned)g.lda * 2u;
+            }
+        }
+        const int n = n0 + lrow;
+        if (n < g.N) b_base = (unsigned)n * (unsigned)g.ldb * 2u;
+    }
+    int tap = 0, ci0 = 0;                                            // conv: block-uniform (tap, ci) of the NEXT tile to issue
+    if (CONV) {
+        const int k = kt0 * BK;
+        tap = k / cg.ci;
+        ci0 = k - tap * cg.ci;
+    }
+    const unsigned lds_wave = (unsigned)wave * 1024u;               // this wave's 1 KiB inside an 8 KiB tile
+
+    auto issue = [&](int kt, int slot) {
+        unsigned char* sa = smem + slot * (2 * TILE_BYTES);
+        unsigned va, vb;
+        if (CONV) {
+            const int px = a_b >= 0 ? conv_src_pixel<CMODE>(cg, a_b, a_oy, a_ox, tap) : -1;
+            va = px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)(ci0 + lchunk)) * 2u : OOB;
+            ci0 += BK;
+            if (ci0 >= cg.ci) { ci0 = 0; ++tap; }
+        } else {
+            va = a_base != OOB ? a_base + (unsigned)(kt * BK + lchunk) * 2u : OOB;
+        }
+        vb = b_base != OOB ? b_base + (unsigned)(kt * BK + lchunk) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + lds_wave), 16, (int)va, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + TILE_BYTES + lds_wave), 16, (int)vb, 0, 0, 0);
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: row r = lane&15 of a 16-row MFMA tile, logical chunk g = lane>>4 -> physical g ^ ((r>>2)&3)
+    const int fr = lane & 15;
+    const int fchunk = ((lane >> 4) ^ ((fr >> 2) & 3)) * 16;         // byte offset inside the 64-byte row
+    const unsigned a_foff = (unsigned)(wm * 32 + fr) * 64u + fchunk;
+    const unsigned b_foff = (unsigned)(wn * 64 + fr) * 64u + fchunk;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (kt0 + s < kt1) issue(kt0 + s, s);
+
+    int slot = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int ahead = min(STAGES - 2, kt1 - 1 - kt);            // younger K-steps already in flight (2 DMA each)
+        if (ahead >= 2) wait_vmcnt<4>();
+        else if (ahead == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, (slot + STAGES - 1) % STAGES);
+        const unsigned char* sa = smem + slot * (2 * TILE_BYTES);
+        const unsigned char* sb = sa + TILE_BYTES;
+        bf16x8 af[2], bf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_foff + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_foff + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+        slot = (slot + 1) % STAGES;
+    }
+
+    // ---------------------------------------------------------------- epilogue (same contract as gemm.hip)
+    const bool first = blockIdx.y == 0;
+    const bool atomic = gridDim.y > 1;
+    const bool f32out = g.out_f32 != 0;
+    const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
+    constexpr int SROW = 132;
+    float* stage = reinterpret_cast<float*>(smem);
+    static_assert(64 * SROW * 4 <= STAGES * 2 * TILE_BYTES, "staging image must fit the ring");
+    float* Cf = reinterpret_cast<float*>(g.C);
+    bf16* Ct = reinterpret_cast<bf16*>(g.C);
+    const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if ((wm >> 1) == pass) {
+            const int lrb = (wm & 1) * 32;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                    *reinterpret_cast<f32x4*>(stage + (lrb + i * 16 + (lane & 15)) * SROW + wn * 64 + j * 16 + (lane >> 4) * 4) = v;
+                }
+        }
+        __syncthreads();
+        if (atomic) {
+            for (int rr = 0; rr < 8; ++rr) {
+                const int lr2 = wave * 8 + rr, m = m0 + pass * 64 + lr2;
+                if (m >= g.M) break;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int n = n0 + h * 64 + lane;
+                    if (n < g.N) {
+                        float v = stage[lr2 * SROW + h * 64 + lane];
+                        if (first) {
+                            if (g.bias) v += g.bias[n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (Rp) v += (float)Rp[(long)m * g.ldr + n];
+                        }
+                        unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
+                    }
+                }
+            }
+        } else {
+            const int lr2 = tid >> 3, seg = (tid & 7) * 16;
+            const int m = m0 + pass * 64 + lr2;
+            if (m < g.M) {
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+#pragma unroll
+                for (int c8 = 0; c8 < 2; ++c8) {
+                    const int n = n0 + seg + c8 * 8;
+                    if (n >= g.N) break;
+                    float v[8];
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + seg + c8 * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + seg + c8 * 8 + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+                    const long off = (long)m * g.ldc + n;
+                    if (vec8) {
+                        if (g.bias) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (rv) {
+                            const float4 b0 = *reinterpret_cast<const float4*>(rv + n), b1 = *reinterpret_cast<const float4*>(rv + n + 4);
+                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        }
+                        if (Rp) {
+                            const bf16x8 rr = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += (float)rr[r];
+                        }
+                        if (f32out) {
+                            float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                            if (g.accumulate) {
+                                const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
+                                o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+                            }
+                            *reinterpret_cast<float4*>(Cf + off) = o0;
+                            *reinterpret_cast<float4*>(Cf + off + 4) = o1;
+                        } else {
+                            if (g.accumulate) {
+                                const bf16x8 c = *reinterpret_cast<const bf16x8*>(Ct + off);
+#pragma unroll
+                                for (int r = 0; r < 8; ++r) v[r] += (float)c[r];
+                            }
+                            bf16x8 o;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                            *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                        }
+                    } else {
+                        const int nv = min(8, g.N - n);
+                        for (int r = 0; r < nv; ++r) {
+                            float x = v[r];
+                            if (g.bias) x += g.bias[n + r];
+                            if (rv) x += rv[n + r];
+                            if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
+                            if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
+                            else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pdmk_dma
+
+// called by pdmk_gemm (gemm.hip) after argument validation; returns 1 if the shape is not handled here
+int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes) {
+    using namespace pdmk_dma;
+    if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
+    if (g.K % BK) return 1;
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    dim3 grid(mt * nt, g.splitk > 1 ? g.splitk : 1);
+#define PDMK_DMA_GO(CV, CM) \
+    hipLaunchKernelGGL((igemm_dma_kernel<CV, CM>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes)
+    if (g.a_mode == PDMK_A_ROWK) PDMK_DMA_GO(false, 0);
+    else {
+        switch (g.conv_mode) {
+            case 0: PDMK_DMA_GO(true, 0); break;
+            case 1: PDMK_DMA_GO(true, 1); break;
+            case 2: PDMK_DMA_GO(true, 2); break;
+            default: PDMK_DMA_GO(true, 3); break;
+        }
+    }
+#undef PDMK_DMA_GO
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
