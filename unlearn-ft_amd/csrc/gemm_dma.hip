@@ -12,8 +12,8 @@
 
 namespace pdmk_dma {
 
-constexpr int BM = 128, BN = 128, BK = 32, NT = 512, STAGES = 4;
-constexpr int TILE_BYTES = 128 * BK * 2;               // 8 KiB per operand per slot
+constexpr int BN = 128, BK = 32, NT = 512;
+constexpr int TILE_BYTES = 128 * BK * 2;               // 8 KiB per 128 tile rows per slot
 constexpr unsigned OOB = 0x80000000u;
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -38,15 +38,25 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
 template <int N> __device__ __forceinline__ void wait_vmcnt();
 template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<2>() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<3>() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 
-template <bool CONV, int CMODE>
+// BM = 128: 4-slot ring of 16 KiB (2 workgroups/CU, 32x64 outputs per wave);  BM = 256: 3-slot ring of 24 KiB (A 256x32 +
+// B 128x32; 72 KiB -> still 2 workgroups/CU, 64x64 per wave): 33 % fewer operand bytes per FLOP into the CU, which is
+// what bounds these kernels (~30 B/cycle/CU of L2->LDS intake), and twice the MFMAs per barrier.
+template <bool CONV, int CMODE, int BM>
 __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
     typedef Mma<bf16> MM;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * 2 * TILE_BYTES];
+    constexpr int AR = BM / 128;                           // A row-blocks of 128 per tile = A DMA instructions per stage
+    constexpr int STAGES = BM == 128 ? 4 : 3;
+    constexpr int SLOT_BYTES = (AR + 1) * TILE_BYTES;
+    constexpr int IM = BM / 64;                            // 16-row MFMA tiles per wave (4 x 2 waves)
+    constexpr int NDMA = AR + 1;                           // DMA instructions per thread and stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves, 32 x 64 outputs each
+    const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves, (BM/4) x 64 outputs each
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
@@ -63,21 +73,25 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     // ---- loader state: thread -> (tile row = tid>>2, physical 16-byte chunk = tid&3); logical chunk = phys ^ swizzle
     const int lrow = tid >> 2;
     const int lchunk = ((tid & 3) ^ ((lrow >> 2) & 3)) * 8;          // element offset inside the 32-wide k-tile
-    unsigned a_base = OOB, b_base = OOB;
-    int a_b = -1, a_oy = 0, a_ox = 0;
-    {
-        const int m = m0 + lrow;
+    unsigned a_base[AR], b_base = OOB;
+    int a_b[AR], a_oy[AR], a_ox[AR];
+#pragma unroll
+    for (int s = 0; s < AR; ++s) {
+        a_base[s] = OOB; a_b[s] = -1; a_oy[s] = 0; a_ox[s] = 0;
+        const int m = m0 + s * 128 + lrow;
         if (m < g.M) {
             if (CONV) {
                 const int hw = cg.ho * cg.wo;
-                a_b = m / hw;
-                const int rem = m - a_b * hw;
-                a_oy = rem / cg.wo;
-                a_ox = rem - a_oy * cg.wo;
+                a_b[s] = m / hw;
+                const int rem = m - a_b[s] * hw;
+                a_oy[s] = rem / cg.wo;
+                a_ox[s] = rem - a_oy[s] * cg.wo;
             } else {
-                a_base = (unsigned)m * (unsigned)g.lda * 2u;
+                a_base[s] = (unsigned)m * (unsigned)g.lda * 2u;
             }
         }
+    }
+    {
         const int n = n0 + lrow;
         if (n < g.N) b_base = (unsigned)n * (unsigned)g.ldb * 2u;
     }
@@ -90,31 +104,36 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     const unsigned lds_wave = (unsigned)wave * 1024u;               // this wave's 1 KiB inside an 8 KiB tile
 
     auto issue = [&](int kt, int slot) {
-        unsigned char* sa = smem + slot * (2 * TILE_BYTES);
-        unsigned va, vb;
+        unsigned char* sa = smem + slot * SLOT_BYTES;
+#pragma unroll
+        for (int s = 0; s < AR; ++s) {
+            unsigned va;
+            if (CONV) {
+                const int px = a_b[s] >= 0 ? conv_src_pixel<CMODE>(cg, a_b[s], a_oy[s], a_ox[s], tap) : -1;
+                va = px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)(ci0 + lchunk)) * 2u : OOB;
+            } else {
+                va = a_base[s] != OOB ? a_base[s] + (unsigned)(kt * BK + lchunk) * 2u : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + s * TILE_BYTES + lds_wave), 16, (int)va, 0, 0, 0);
+        }
         if (CONV) {
-            const int px = a_b >= 0 ? conv_src_pixel<CMODE>(cg, a_b, a_oy, a_ox, tap) : -1;
-            va = px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)(ci0 + lchunk)) * 2u : OOB;
             ci0 += BK;
             if (ci0 >= cg.ci) { ci0 = 0; ++tap; }
-        } else {
-            va = a_base != OOB ? a_base + (unsigned)(kt * BK + lchunk) * 2u : OOB;
         }
-        vb = b_base != OOB ? b_base + (unsigned)(kt * BK + lchunk) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + lds_wave), 16, (int)va, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + TILE_BYTES + lds_wave), 16, (int)vb, 0, 0, 0);
+        const unsigned vb = b_base != OOB ? b_base + (unsigned)(kt * BK + lchunk) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + AR * TILE_BYTES + lds_wave), 16, (int)vb, 0, 0, 0);
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[IM][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses: row r = lane&15 of a 16-row MFMA tile, logical chunk g = lane>>4 -> physical g ^ ((r>>2)&3)
     const int fr = lane & 15;
     const int fchunk = ((lane >> 4) ^ ((fr >> 2) & 3)) * 16;         // byte offset inside the 64-byte row
-    const unsigned a_foff = (unsigned)(wm * 32 + fr) * 64u + fchunk;
+    const unsigned a_foff = (unsigned)(wm * (16 * IM) + fr) * 64u + fchunk;
     const unsigned b_foff = (unsigned)(wn * 64 + fr) * 64u + fchunk;
 
 #pragma unroll
@@ -123,21 +142,21 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
 
     int slot = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int ahead = min(STAGES - 2, kt1 - 1 - kt);            // younger K-steps already in flight (2 DMA each)
-        if (ahead >= 2) wait_vmcnt<4>();
-        else if (ahead == 1) wait_vmcnt<2>();
+        const int ahead = min(STAGES - 2, kt1 - 1 - kt);            // younger K-steps already in flight (NDMA each)
+        if (ahead >= 2) wait_vmcnt<2 * NDMA>();
+        else if (ahead == 1) wait_vmcnt<NDMA>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, (slot + STAGES - 1) % STAGES);
-        const unsigned char* sa = smem + slot * (2 * TILE_BYTES);
-        const unsigned char* sb = sa + TILE_BYTES;
-        bf16x8 af[2], bf[4];
+        const unsigned char* sa = smem + slot * SLOT_BYTES;
+        const unsigned char* sb = sa + AR * TILE_BYTES;
+        bf16x8 af[IM], bf[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_foff + i * 1024);
+        for (int i = 0; i < IM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_foff + i * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_foff + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < IM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
         slot = (slot + 1) % STAGES;
@@ -150,17 +169,18 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
     constexpr int SROW = 132;
     float* stage = reinterpret_cast<float*>(smem);
-    static_assert(64 * SROW * 4 <= STAGES * 2 * TILE_BYTES, "staging image must fit the ring");
+    static_assert(64 * SROW * 4 <= STAGES * SLOT_BYTES, "staging image must fit the ring");
+    static_assert(2 * NDMA <= 4 || NDMA == 3, "wait_vmcnt instantiations");
     float* Cf = reinterpret_cast<float*>(g.C);
     bf16* Ct = reinterpret_cast<bf16*>(g.C);
     const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < BM / 64; ++pass) {
         __syncthreads();
-        if ((wm >> 1) == pass) {
-            const int lrb = (wm & 1) * 32;
+        if ((wm * 16 * IM) / 64 == pass) {
+            const int lrb = (wm * 16 * IM) % 64;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = acc[i][j];
@@ -260,10 +280,18 @@ int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, 
     using namespace pdmk_dma;
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if (g.K % BK) return 1;
-    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    const int nt = (g.N + BN - 1) / BN;
+    // 256-row tiles when they still give every CU its two workgroups' worth of blocks (the 64x64-latent layers)
+    const bool big = (long)((g.M + 255) / 256) * nt * (g.splitk > 1 ? g.splitk : 1) >= 320;
+    const int mt = big ? (g.M + 255) / 256 : (g.M + 127) / 128;
     dim3 grid(mt * nt, g.splitk > 1 ? g.splitk : 1);
-#define PDMK_DMA_GO(CV, CM) \
-    hipLaunchKernelGGL((igemm_dma_kernel<CV, CM>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes)
+#define PDMK_DMA_GO(CV, CM)                                                                                           \
+    do {                                                                                                              \
+        if (big) hipLaunchKernelGGL((igemm_dma_kernel<CV, CM, 256>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes,    \
+                                    (unsigned)b_bytes);                                                               \
+        else hipLaunchKernelGGL((igemm_dma_kernel<CV, CM, 128>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes,        \
+                                (unsigned)b_bytes);                                                                   \
+    } while (0)
     if (g.a_mode == PDMK_A_ROWK) PDMK_DMA_GO(false, 0);
     else {
         switch (g.conv_mode) {
