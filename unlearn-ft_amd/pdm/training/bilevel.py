@@ -144,6 +144,10 @@ class BilevelStepper:
         self.reducer = GradReducer(student.store, bucket_mb)
         self.defer_reduce = False
         self._gscale = 1.0 / world
+        # the frozen teacher pass and the student forward are independent until the loss heads: they run on two HIP
+        # streams (two parallel branches once captured in a hipGraph) so the small-grid layers of one fill the CUs the
+        # other leaves idle
+        self.teacher_stream = torch.cuda.Stream(device=self.dev)
         self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused)
 
     # ------------------------------------------------------------------ pieces
@@ -197,9 +201,14 @@ class BilevelStepper:
         noisy, target = self._diffuse(latents, noise, timesteps, True)
         ehs = self._ehs2d(prompt_embeds)
         self.losses.zero_()
+        cur = torch.cuda.current_stream()
         if need_teacher:
-            pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
+            self.teacher_stream.wait_stream(cur)
+            with torch.cuda.stream(self.teacher_stream):
+                pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
         pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        if need_teacher:
+            cur.wait_stream(self.teacher_stream)
         wb = self.snr_w[timesteps].contiguous()
         HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
         k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
@@ -228,11 +237,15 @@ class BilevelStepper:
         noisy2 = torch.cat([noisy, noisy], 0)
         t2 = torch.cat([timesteps, timesteps], 0)
         self.losses.zero_()
-        pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
+        cur = torch.cuda.current_stream()
+        self.teacher_stream.wait_stream(cur)
+        with torch.cuda.stream(self.teacher_stream):
+            pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
+        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        cur.wait_stream(self.teacher_stream)
         M = B * H * W
         e_c, e_u = pred_t.t[:M], pred_t.t[M:]
         k.axpby(e_c, e_u, -1.0, 2.0)               # e_u <- 2 e_u - e_c  == e_u - (e_c - e_u)
-        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
         cp, n = pred.t.shape[1], M * C
         k.mse_fwd(pred.t, e_u, None, self.losses, 1, B, H * W, C, cp, cp, 1.0 / n)
         if backward:
