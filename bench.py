@@ -36,6 +36,7 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--no_graph", action="store_true", help="eager Python launches instead of hipGraph replay")
+    p.add_argument("--force_graph", action="store_true", help="hipGraph replay also for N > 1 (all-reduce not overlapped)")
     return p.parse_args()
 
 
@@ -126,8 +127,13 @@ def main():
         st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], empty)
         st.optimizer_step(upper=True)
 
+    # 1 GPU: hipGraph replay (immune to host jitter).  N > 1: eager multi-stream launches, because there the bucketed
+    # RCCL all-reduce is issued from the backward tape and overlaps with the rest of the backward pass (in graph mode
+    # it would run exposed between the two graphs); eager and graph mode are equally fast on one GPU since the
+    # teacher / wgrad side streams keep the queues full.  --force_graph / --no_graph override.
+    use_graph = (world == 1 and not a.no_graph) or a.force_graph
     graphs = None
-    if not a.no_graph:
+    if use_graph:
         graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
         graphs.capture(bilevel=True)
 

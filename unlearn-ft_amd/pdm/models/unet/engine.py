@@ -41,6 +41,11 @@ class UNetEngine:
         self.macs = 0
         self.count_macs = False
         self.grad_ready_cb = None      # called with an arena offset: every gradient at or beyond it is final
+        # weight-gradient GEMMs only feed the optimiser: they run on a side stream (a parallel branch of the captured
+        # graph) next to the dgrad chain, which is the critical path of the backward pass
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev)
+        self.wgrad_async = True
+        self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -61,6 +66,23 @@ class UNetEngine:
             act.g = dy
         else:
             k.copy2d(dy, act.g, dy.shape[0], dy.shape[1], _ld(dy), _ld(act.g), accumulate=True)
+
+    def _wgrad(self, fn, *operands):
+        """Launch a weight-gradient kernel.  Side stream: it starts once everything queued on the main stream so far
+        (in particular dy) is done; its operands stay referenced until the next join."""
+        if not self.wgrad_async:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        self.wgrad_stream.wait_stream(main)
+        with torch.cuda.stream(self.wgrad_stream):
+            fn()
+        self._keep.extend(operands)
+
+    def _join_wgrad(self):
+        if self.wgrad_async and self._keep:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+            self._keep.clear()
 
     @staticmethod
     def _splitk(m_out, n_out, red, step):
@@ -96,9 +118,12 @@ class UNetEngine:
                     k.gemm_auto(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc,
                                 macs=lmacs)
                 sk = self._splitk(Np, Kp, M, 64)
-                k.gemm(dy, x.t, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(x.t), Kp, a_mode=k.A_COLK,
-                       b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs,
-                       colsum_out=P.g(bias) if bias else None)        # bias gradient fused into the wgrad pass
+                xt = x.t
+                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), Kp,
+                                           a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
+                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
+                                           colsum_out=P.g(bias) if bias else None),   # bias gradient fused in
+                            dy, xt)
                 if residual is not None:
                     self._give(residual, out.g)
             self.tape.append(bwd)
@@ -140,10 +165,13 @@ class UNetEngine:
                                     a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
                                accumulate=acc, macs=lmacs)
                 sk = self._splitk(Cop, 9 * Cip, M, 64)
-                k.gemm(dy, x.t, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip, a_mode=k.A_COLK,
-                       b_mode=k.B_COLK_CONV, conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), out_f32=True, splitk=sk,
-                       accumulate=(sk == 1), dtype=k.dt(x.t), macs=lmacs,
-                       colsum_out=None if rowvec is not None else P.g(bias))
+                xt = x.t
+                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip,
+                                           a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
+                                           conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), out_f32=True, splitk=sk,
+                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
+                                           colsum_out=None if rowvec is not None else P.g(bias)),
+                            dy, xt)
                 if rowvec is not None:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
                     dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
@@ -265,7 +293,12 @@ class UNetEngine:
         gradient from this block's first arena entry to the end of the arena is final (bucketed all-reduce trigger)."""
         if self.train:
             off = self.P.by_key[first_key].off
-            self.tape.append(lambda: self.grad_ready_cb(off) if self.grad_ready_cb else None)
+
+            def mark():
+                self._join_wgrad()         # block boundary: side-stream wgrads of this block are done, operands freed
+                if self.grad_ready_cb:
+                    self.grad_ready_cb(off)
+            self.tape.append(mark)
 
     def resblock(self, x, r, st, B, H, W):
         G = self.cfg.norm_num_groups
@@ -362,3 +395,4 @@ class UNetEngine:
         tape, self.tape = self.tape, []
         for fn in reversed(tape):
             fn()
+        self._join_wgrad()
