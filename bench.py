@@ -129,9 +129,11 @@ def main():
 
     # 1 GPU: hipGraph replay (immune to host jitter).  N > 1: eager multi-stream launches, because there the bucketed
     # RCCL all-reduce is issued from the backward tape and overlaps with the rest of the backward pass (in graph mode
-    # it would run exposed between the two graphs); eager and graph mode are equally fast on one GPU since the
-    # teacher / wgrad side streams keep the queues full.  --force_graph / --no_graph override.
+    # it would run exposed between the two graphs); eager mode also moves the weight-gradient GEMMs to a side stream,
+    # which keeps the queues full while Python launches (measured: eager 55.3 vs graph 55.0 ms per main step on one
+    # GPU; inside a graph the side stream costs 2%, so it stays off there).  --force_graph / --no_graph override.
     use_graph = (world == 1 and not a.no_graph) or a.force_graph
+    student.engine.wgrad_async = not use_graph
     graphs = None
     if use_graph:
         graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)

@@ -196,3 +196,22 @@ def test_full_size_sd21_main_step_matches_oracle(dev, dn):
     if dn == "bf16":        # the backward ran: gradients are finite and the packed padding carries none
         gsum = float(student.store.grad.double().abs().sum())
         assert math.isfinite(gsum) and gsum > 0
+
+
+def test_side_stream_wgrad_matches_in_stream(dev):
+    """engine.wgrad_async moves the weight-gradient GEMMs to a second HIP stream (eager multi-GPU mode); the gradients
+    must not depend on it (regression test for a read-after-alias race on residual layers)."""
+    from pdm.training.bilevel import BilevelStepper
+    ocfg, dense, psd, info, student, teacher = _setup(torch.float32)
+    lat, noise, t, ehs, _ = _inputs()
+    st = BilevelStepper(student, teacher)
+    grads = []
+    for mode in (False, True, True):
+        student.engine.wgrad_async = mode
+        student.store.grad.zero_()
+        st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+        torch.cuda.synchronize()
+        grads.append(student.store.state_dict(arena=student.store.grad))
+    for other in grads[1:]:
+        worst = max((_rel(other[n], grads[0][n]), n) for n in grads[0])
+        assert worst[0] < 1e-4, worst

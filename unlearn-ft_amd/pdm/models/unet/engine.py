@@ -8,6 +8,7 @@ Gradient fan-in (residuals, skip connections, the shared time embedding) is done
 (accumulate flags) or by aliasing a finished gradient buffer - there are no standalone "add" passes on the hot path.
 """
 import math
+import os
 
 import torch
 
@@ -44,7 +45,7 @@ class UNetEngine:
         # weight-gradient GEMMs only feed the optimiser: they run on a side stream (a parallel branch of the captured
         # graph) next to the dgrad chain, which is the critical path of the backward pass
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)
-        self.wgrad_async = True
+        self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
 
     # ------------------------------------------------------------------ helpers
@@ -84,6 +85,12 @@ class UNetEngine:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._keep.clear()
 
+    def _wgrad_fence(self):
+        """The gradient buffer a side-stream wgrad is reading is about to be handed on (aliased) and accumulated into
+        in place by later main-stream kernels: make the main stream wait for the side stream first."""
+        if self.wgrad_async:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
     @staticmethod
     def _splitk(m_out, n_out, red, step):
         tiles = ((m_out + 127) // 128) * ((n_out + 127) // 128)
@@ -113,18 +120,20 @@ class UNetEngine:
                     dyc = self._empty(M, Np)
                     k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
                     dy = dyc
-                if x.rg:
-                    dx, acc = self._grad_into(x, M, Kp)
-                    k.gemm_auto(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc,
-                                macs=lmacs)
                 sk = self._splitk(Np, Kp, M, 64)
                 xt = x.t
+                # wgrad first (side stream), dgrad second (main stream): the two GEMMs of one layer run side by side
                 self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), Kp,
                                            a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
                                            accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
                                            colsum_out=P.g(bias) if bias else None),   # bias gradient fused in
                             dy, xt)
+                if x.rg:
+                    dx, acc = self._grad_into(x, M, Kp)
+                    k.gemm_auto(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc,
+                                macs=lmacs)
                 if residual is not None:
+                    self._wgrad_fence()
                     self._give(residual, out.g)
             self.tape.append(bwd)
         return out
@@ -151,6 +160,14 @@ class UNetEngine:
             def bwd():
                 dy = out.g
                 ldy = _ld(dy)
+                sk = self._splitk(Cop, 9 * Cip, M, 64)
+                xt = x.t
+                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip,
+                                           a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
+                                           conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), out_f32=True, splitk=sk,
+                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
+                                           colsum_out=None if rowvec is not None else P.g(bias)),
+                            dy, xt)
                 if x.rg:
                     if mode == 2:
                         tmp = self._empty(M, Cip)
@@ -164,14 +181,6 @@ class UNetEngine:
                         k.gemm_auto(dy, P.wtv(key + ".weight"), dx, B * Hi * Wi, Cip, 9 * Cop, 0, 9 * Cop, _ld(dx),
                                     a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
                                accumulate=acc, macs=lmacs)
-                sk = self._splitk(Cop, 9 * Cip, M, 64)
-                xt = x.t
-                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip,
-                                           a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
-                                           conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), out_f32=True, splitk=sk,
-                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
-                                           colsum_out=None if rowvec is not None else P.g(bias)),
-                            dy, xt)
                 if rowvec is not None:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
                     dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
@@ -180,6 +189,7 @@ class UNetEngine:
                     k.colsum(dtp, P.g(bias), B, Cop, Cop, accumulate=True)
                     rowvec.g = dtp
                 if residual is not None:
+                    self._wgrad_fence()
                     self._give(residual, dy)
             self.tape.append(bwd)
         return out, Ho, Wo
