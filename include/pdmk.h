@@ -77,6 +77,12 @@ typedef struct pdmk_gemm_args {
 } pdmk_gemm_args;
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
+/* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller
+ * should use (1 = plain call; > 1 = accumulate fp32 partials into a zeroed [M,N] workspace with out_f32 + splitk, then
+ * pdmk_splitk_finish).  The first time a shape is seen outside stream capture the library times its candidate kernels
+ * (tile shapes x split factors) on the device, blocking the host for a few ms, and caches the winner for the process;
+ * inside a capture, or with PDMK_GEMM_TUNE=0, a static heuristic answers instead. */
+int pdmk_gemm_plan(const pdmk_gemm_args* args, pdmk_stream stream, int32_t* splitk_out);
 /* Second half of a split-K forward/dgrad GEMM (small-M layers at 8x8 / 16x16 latents: too few output tiles to fill 256
  * CUs): pdmk_gemm accumulated fp32 partials into the zeroed workspace ws[M,N] (out_f32, splitk>1); this applies the
  * epilogue C = (accumulate ? C : 0) + ws + bias + rowvec + R and stores in `dtype`. */
@@ -186,6 +192,15 @@ int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, const float* l
  * {src_off(lo,hi), dst_off(lo,hi), rows, cols, src_ld, dst_ld, r0, c0, 0, 0}; each record transposes one 64x64 tile:
  * dst[dst_off + c*dst_ld + r] = src[src_off + r*src_ld + c]. src/dst in `dtype`. */
 int pdmk_transpose_tiles(const void* src, void* dst, const int32_t* table, int ntiles, int dtype, pdmk_stream stream);
+/* Skinny linears, M <= 16 rows (the time-embedding MLP and every ResBlock's time_emb_proj run with M = batch:
+ * unet_2d_conditional.py:1514-1533, blocks.py:334-341).  Weight-streaming dot products instead of MFMA tiles.
+ *   gemm : y[m][n] = (accumulate ? y : 0) + sum_k x[m][k] w[n][k] + bias[n]; x in x_dtype (bf16/fp32), w in dtype,
+ *          y fp32 (out_f32) or dtype.  The dgrad is the same call with w = W^T.
+ *   wgrad: dw[n][k] += sum_m dy[m][n] x[m][k];  dbias[n] += sum_m dy[m][n]  (dbias may be NULL); dw/dbias fp32. */
+int pdmk_skinny_gemm(const void* x, int x_dtype, const void* w, void* y, const float* bias, int M, int N, int K,
+                     int ldx, int ldw, int ldy, int dtype, int out_f32, int accumulate, pdmk_stream stream);
+int pdmk_skinny_wgrad(const void* dy, int dy_dtype, const void* x, float* dw, float* dbias, int M, int N, int K,
+                      int lddy, int ldx, int lddw, int dtype, pdmk_stream stream);
 /* sum of squares of n floats into out[slot] (double) — gradient-norm clipping (trainer.py:2323-2325). */
 int pdmk_sumsq(const float* x, int64_t n, double* out, int slot, pdmk_stream stream);
 

@@ -368,3 +368,34 @@ def test_scalar_kernels(dev):
     ss = torch.zeros(2, device=dev, dtype=torch.float64)
     k.sumsq(p0, n, ss, 1)
     close(ss[1:2], (p0.double() ** 2).sum().view(1), 1e-6, "sumsq")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(8, 1280, 320), (2, 136, 64), (8, 336, 1280), (16, 64, 96), (1, 8, 32)])
+def test_skinny_gemm_and_wgrad(dev, dn, M, N, K):
+    """pdmk_skinny_gemm / pdmk_skinny_wgrad (time-embedding linears, M = batch) vs fp32 torch."""
+    from pdm import _pdmk as k
+    torch.manual_seed(5)
+    dt = DT[dn]
+    x, w = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5)
+    bias = torch.randn(N, device=dev)
+    ref = x.float() @ w.float().t() + bias
+    for ydt in (torch.float32, dt):
+        y = torch.full((M, N), 7.0, device=dev, dtype=ydt)
+        k.skinny_gemm(x, w, y, M, N, K, K, K, N, bias=bias)
+        close(y, ref, TOL[dn], "skinny gemm")
+        y2 = y.clone()
+        k.skinny_gemm(x, w, y2, M, N, K, K, K, N, accumulate=True)
+        close(y2, y.float() + x.float() @ w.float().t(), TOL[dn], "skinny gemm accumulate")
+    # dgrad form: fp32 skinny operand against compute-dtype weights
+    dyf = torch.randn(M, N, device=dev)
+    wt = w.t().contiguous()
+    dx = torch.zeros(M, K, device=dev, dtype=dt)
+    k.skinny_gemm(dyf, wt, dx, M, K, N, N, N, K)
+    close(dx, dyf @ w.float(), TOL[dn], "skinny dgrad")
+    for dy in (dyf, dyf.to(dt)) if dn == "bf16" else (dyf,):
+        dw = torch.ones(N, K, device=dev)
+        db = torch.ones(N, device=dev)
+        k.skinny_wgrad(dy, x, dw, db, M, N, K, N, K, K)
+        close(dw, 1.0 + dy.float().t() @ x.float(), TOL[dn], "skinny wgrad")
+        close(db, 1.0 + dy.float().sum(0), TOL[dn], "skinny bias grad")

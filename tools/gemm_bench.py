@@ -61,7 +61,7 @@ def wgrad_conv(B, H, Ci, Co, sk):
     return f"wgrad-conv B{B} {H}x{H} {Ci}->{Co} sk{sk}", 2.0 * P * Co * 9 * Ci, t
 
 
-rows = [conv(8, 64, 320, 320), conv(8, 64, 960, 176), conv(8, 32, 640, 640), conv(8, 16, 1280, 1280), conv(8, 8, 1280, 1280),
+rows = [lin(8192, 8192, 8192), lin(4096, 4096, 4096), lin(32768, 1024, 1024), lin(16384, 2048, 512), conv(8, 64, 320, 320), conv(8, 64, 960, 176), conv(8, 32, 640, 640), conv(8, 16, 1280, 1280), conv(8, 8, 1280, 1280),
         conv(8, 8, 2560, 1280), conv(8, 64, 320, 320, 1), conv(8, 32, 640, 640, 2),
         lin(32768, 320, 320, True), lin(32768, 960, 320), lin(32768, 2560, 320), lin(32768, 320, 1280, True), lin(8192, 640, 640, True),
         lin(2048, 1280, 1280, True), lin(616, 640, 1024), lin(32768, 320, 960),

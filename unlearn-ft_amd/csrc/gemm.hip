@@ -12,7 +12,11 @@
 // transposed by ds_read_b64_tr_b16 on the way into the MFMA fragments.  The MFMA is issued with operands swapped
 // (D = B.A^T) so a lane ends up with 4 consecutive n of one output row: 8/16-byte epilogue loads and stores.
 // Blocks are remapped so that the n-tiles of one m-tile run back to back on one XCD (shared activation panel in L2).
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
 
 #include "common.h"
 
@@ -470,15 +474,165 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
 }  // namespace
 
 int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes);   // gemm_dma.hip
+int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id);  // gemm_ring.hip
+int pdmk_gemm_ring_num_configs();
+int pdmk_gemm_ring_pick(const pdmk_gemm_args& g);
 
-static int dma_mode() {        // PDMK_GEMM_DMA=0 forces the register-staged kernel everywhere (A/B testing)
-    static int m = -1;
-    if (m < 0) {
-        const char* e = getenv("PDMK_GEMM_DMA");
-        m = e ? atoi(e) : 1;
+static int env_int(const char* name, int def, int* cache) {     // cached unless PDMK_ENV_DYNAMIC is set (A/B tools)
+    static int dynamic = -1;
+    if (dynamic < 0) dynamic = getenv("PDMK_ENV_DYNAMIC") ? 1 : 0;
+    if (*cache == INT32_MIN || dynamic) {
+        const char* e = getenv(name);
+        *cache = e ? atoi(e) : def;
     }
-    return m;
+    return *cache;
 }
+static int dma_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_DMA", 1, &c); }    // 0: register-staged only
+static int ring_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_RING", 1, &c); }  // 0: K-step-32 kernels only
+static int tune_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_TUNE", 1, &c); }  // 0: heuristics only
+static int forced_cfg() { static int c = INT32_MIN; return env_int("PDMK_RING_CFG", -1, &c); } // >= 0: that candidate id
+
+// ---------------------------------------------------------------------------------------------------------------
+// Plan cache.  The forward / dgrad GEMMs of the step come in ~200 shapes whose best tile shape, ring depth and split-K
+// factor depend on how the grid quantises onto 256 CUs; instead of modelling that, every new shape is timed once on
+// the device (candidates: the K-step-32 kernels and the LDS-DMA ring shapes of gemm_ring.hip; 3 launches each into a
+// scratch output) the first time it is seen outside stream capture, and the winner is cached for the process.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PlanKey {
+    int v[9];
+    bool operator<(const PlanKey& o) const { return memcmp(v, o.v, sizeof v) < 0; }
+};
+std::mutex g_plan_mu;
+std::map<PlanKey, int> g_plan_cfg;   // (shape, splitk) -> candidate id (0 = K-step-32 kernels, 1 + ring config id)
+std::map<PlanKey, int> g_plan_sk;    // shape -> split-K factor
+void* g_scratch = nullptr;
+size_t g_scratch_bytes = 0;
+
+PlanKey make_key(const pdmk_gemm_args& g, int sk) {
+    PlanKey k;
+    const bool cv = g.a_mode == PDMK_A_CONV;
+    const int v[9] = {g.M, g.N, g.K, g.a_mode, cv ? g.conv_mode : 0, cv ? g.conv_hi : 0, cv ? g.conv_wi : 0,
+                      cv ? g.conv_ci : 0, sk};
+    memcpy(k.v, v, sizeof v);
+    return k;
+}
+
+bool ring_eligible(const pdmk_gemm_args& g) {
+    return g.dtype == PDMK_BF16 && g.b_mode == PDMK_B_ROWK && g.a_mode != PDMK_A_COLK;
+}
+
+bool operand_bytes(const pdmk_gemm_args& g, long* ab, long* bb) {
+    const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * 2;
+    *ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2 : conv_bytes;
+    *bb = ((long)(g.N - 1) * g.ldb + g.K) * 2;
+    return *ab < (1L << 31) && *bb < (1L << 31);
+}
+
+int launch_legacy(const pdmk_gemm_args& g, hipStream_t st) {
+    const long nblocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.splitk > 1 ? g.splitk : 1);
+    long ab, bb;
+    if (dma_mode() && (nblocks >= 384 || dma_mode() == 2) && ring_eligible(g) && (g.K % 32) == 0 && operand_bytes(g, &ab, &bb)) {
+        const int rc = pdmk_gemm_dma_launch(g, st, ab, bb);
+        if (rc <= 0) return rc;
+    }
+    return g.dtype == PDMK_BF16 ? launch<bf16>(g, st) : launch<float>(g, st);
+}
+
+int launch_candidate(const pdmk_gemm_args& g, hipStream_t st, int id) {
+    if (id <= 0) return launch_legacy(g, st);
+    long ab, bb;
+    if (!operand_bytes(g, &ab, &bb)) return 1;
+    return pdmk_gemm_ring_launch(g, st, ab, bb, id - 1);
+}
+
+bool can_tune(hipStream_t st) {
+    if (!tune_mode() || !ring_mode()) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs == hipStreamCaptureStatusNone;
+}
+
+bool ensure_scratch(size_t bytes) {
+    if (bytes <= g_scratch_bytes) return true;
+    if (g_scratch) (void)hipFree(g_scratch);
+    g_scratch = nullptr;
+    g_scratch_bytes = 0;
+    if (hipMalloc(&g_scratch, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+    g_scratch_bytes = bytes;
+    return true;
+}
+
+// time `reps` launches of candidate `id` (plus, for split-K, the workspace clear and the finish pass) in microseconds
+float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws, void* fin_out, hipEvent_t e0, hipEvent_t e1) {
+    const int reps = 3;
+    auto once = [&]() -> int {
+        if (a.splitk > 1) {
+            if (hipMemsetAsync(ws, 0, (size_t)a.M * a.N * 4, st) != hipSuccess) return -1;
+            const int rc = launch_candidate(a, st, id);
+            if (rc) return rc;
+            return pdmk_splitk_finish(ws, fin_out, nullptr, nullptr, nullptr, a.M, a.N, a.N, 0, 1, 0, a.dtype, st);
+        }
+        return launch_candidate(a, st, id);
+    };
+    if (once() != 0) { (void)hipGetLastError(); return 1e30f; }
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps; ++r)
+        if (once() != 0) { (void)hipGetLastError(); return 1e30f; }
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.f / reps;
+}
+
+// best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().
+int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
+    const size_t out_bytes = (size_t)g.M * g.N * 4;
+    if (!ensure_scratch(2 * out_bytes + 256)) return -1;
+    (void)hipDeviceSynchronize();                    // other streams (teacher branch) must not overlap the timings
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    pdmk_gemm_args a = g;
+    float* ws = reinterpret_cast<float*>(g_scratch);
+    void* out2 = reinterpret_cast<char*>(g_scratch) + out_bytes;
+    a.accumulate = 0;
+    a.splitk = sk;
+    a.ldc = g.N;
+    if (sk > 1) { a.C = ws; a.out_f32 = 1; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
+    else a.C = out2;
+    int best = -1;
+    float bt = 1e30f;
+    const int ncand = 1 + pdmk_gemm_ring_num_configs();
+    for (int id = 0; id < ncand; ++id) {
+        const float t = time_candidate(a, st, id, ws, out2, e0, e1);
+        if (t < bt) { bt = t; best = id; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("PDMK_TUNE_LOG"))
+        fprintf(stderr, "[pdmk tune] M=%d N=%d K=%d amode=%d cmode=%d sk=%d -> cand %d (%.1f us)\n", g.M, g.N, g.K, g.a_mode,
+                g.conv_mode, sk, best, bt);
+    *t_out = bt;
+    return best;
+}
+
+int heuristic_cfg(const pdmk_gemm_args& g) {
+    if (!ring_mode()) return 0;
+    return 1 + pdmk_gemm_ring_pick(g);
+}
+
+int heuristic_sk(const pdmk_gemm_args& g) {           // untuned default: only deep-K, few-tile GEMMs are split
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int nk = g.K / 64;
+    if (tiles > 160 || nk < 64 || (tiles > 96 && nk < 160) || (g.N & 3)) return 1;
+    const int a = nk / 16, b = (256 + tiles - 1) / tiles;
+    const int s = a < b ? a : b;
+    return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+}  // namespace
 
 extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (!a || !a->A || !a->B || !a->C) return -1;
@@ -508,19 +662,60 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.splitk > 1 && !(g.out_f32 || g.dtype == PDMK_F32)) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    // LDS-DMA ring kernel (gemm_dma.hip) for the large-grid forward / dgrad GEMMs: measured +7..18 % there; the deep-K
-    // small-grid layers (16x16 / 8x8 latents) keep the K-step-64 register-staged kernel (fewer barriers per MFMA)
-    const long nblocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.splitk > 1 ? g.splitk : 1);
-    if (dma_mode() && nblocks >= 384 && g.dtype == PDMK_BF16 && g.b_mode == PDMK_B_ROWK && g.a_mode != PDMK_A_COLK) {
-        const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * 2;
-        const long ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2 : conv_bytes;
-        const long bb = ((long)(g.N - 1) * g.ldb + g.K) * 2;
-        if (ab < (1L << 31) && bb < (1L << 31)) {
-            const int rc = pdmk_gemm_dma_launch(g, st, ab, bb);
-            if (rc <= 0) return rc;
-        }
+    if (!ring_eligible(g) || (g.K % 8)) return launch_legacy(g, st);
+    if (forced_cfg() >= 0) return launch_candidate(g, st, forced_cfg());
+    const int sk = g.splitk > 1 ? g.splitk : 1;
+    int id;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        const PlanKey key = make_key(g, sk);
+        auto it = g_plan_cfg.find(key);
+        if (it != g_plan_cfg.end()) id = it->second;
+        else if (can_tune(st)) {
+            float t;
+            id = tune_cfg(g, st, sk, &t);
+            if (id < 0) id = heuristic_cfg(g);
+            g_plan_cfg[key] = id;
+        } else id = heuristic_cfg(g);                   // not cached: a later eager call may still tune it
     }
-    return g.dtype == PDMK_BF16 ? launch<bf16>(g, st) : launch<float>(g, st);
+    const int rc = launch_candidate(g, st, id);
+    return rc == 1 ? launch_legacy(g, st) : rc;
+}
+
+/* Split-K factor for a forward / dgrad GEMM (1 = do not split); see include/pdmk.h. */
+extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32_t* splitk_out) {
+    if (!a || !splitk_out) return -1;
+    const pdmk_gemm_args& g = *a;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    *splitk_out = 1;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
+    if (g.N & 3) return 0;
+    if (!ring_eligible(g) || (g.K % 8) || forced_cfg() >= 0) {
+        *splitk_out = heuristic_sk(g);
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    const PlanKey key0 = make_key(g, 0);
+    auto it = g_plan_sk.find(key0);
+    if (it != g_plan_sk.end()) { *splitk_out = it->second; return 0; }
+    if (!can_tune(st) || !a->A || !a->B) { *splitk_out = heuristic_sk(g); return 0; }
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int nk = (g.K + 63) / 64;
+    const int cands[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    int best_sk = 1;
+    float bt = 1e30f;
+    for (int c = 0; c < 8; ++c) {
+        const int sk = cands[c];
+        if (sk > 1 && (tiles > 200 || nk < 24 || nk / sk < 6 || (long)tiles * sk > 768)) continue;
+        float t = 1e30f;
+        const int id = tune_cfg(g, st, sk, &t);
+        if (id < 0) continue;
+        g_plan_cfg[make_key(g, sk)] = id;
+        if (t < bt * (sk > 1 ? 0.97f : 1.0f)) { bt = t; best_sk = sk; }     // a split must win by > 3 %
+    }
+    g_plan_sk[key0] = best_sk;
+    *splitk_out = best_sk;
+    return 0;
 }
 
 extern "C" int pdmk_version(void) { return 102; }

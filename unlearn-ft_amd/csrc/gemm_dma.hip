@@ -10,6 +10,20 @@
 //     side (per-lane global address) and on the read side.
 #include "common.h"
 
+#ifdef PDMK_STAMPS      // diagnostic build only: per-workgroup phase timestamps (s_memtime), read back by tools/
+__device__ unsigned long long pdmk_stamps[8192 * 6];
+extern "C" int pdmk_debug_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(pdmk_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#define PDMK_STAMP(i)                                                                                    \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192)                                    \
+            pdmk_stamps[blockIdx.x * 6 + (i)] = (i) >= 4 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PDMK_STAMP(i)
+#endif
+
 namespace pdmk_dma {
 
 constexpr int BN = 128, BK = 32, NT = 512;
@@ -55,6 +69,8 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     constexpr int NDMA = AR + 1;                           // DMA instructions per thread and stage
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT_BYTES];
 
+    PDMK_STAMP(0);
+    PDMK_STAMP(5);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                 // 4 x 2 waves, (BM/4) x 64 outputs each
     const int ntn = (g.N + BN - 1) / BN;
@@ -147,6 +163,9 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
         else if (ahead == 1) wait_vmcnt<NDMA>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+#ifdef PDMK_STAMPS
+        if (kt == kt0) PDMK_STAMP(1);
+#endif
         if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, (slot + STAGES - 1) % STAGES);
         const unsigned char* sa = smem + slot * SLOT_BYTES;
         const unsigned char* sb = sa + AR * TILE_BYTES;
@@ -163,6 +182,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     }
 
     // ---------------------------------------------------------------- epilogue (same contract as gemm.hip)
+    PDMK_STAMP(2);
     const bool first = blockIdx.y == 0;
     const bool atomic = gridDim.y > 1;
     const bool f32out = g.out_f32 != 0;
@@ -271,6 +291,8 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
             }
         }
     }
+    PDMK_STAMP(3);
+    PDMK_STAMP(4);
 }
 
 }  // namespace pdmk_dma

@@ -1,0 +1,376 @@
+// Implicit GEMM, LDS-DMA ring (bf16; A = activation rows or 3x3 gather, B = weights [N][K]): forward / dgrad work-horse.
+//   * K-step 64: every DMA wave-instruction (buffer_load_dwordx4 ... lds, 1 KiB) moves 8 tile rows x 128 B, i.e. FULL
+//     128-byte lines of the source rows (half the texture-addresser work per byte of the 16 x 64 B pieces of a K-step-32
+//     tile); out-of-range lanes (conv halo, M/N/K tails) are zero-filled into LDS by the buffer unit;
+//   * one 512-thread workgroup per CU owns (almost) the whole 160 KiB LDS as a ring of STAGES (A BMx64 + B BNx64) bf16
+//     tiles: STAGES-1 K-steps stay in flight behind a counted s_waitcnt vmcnt(N) + one raw s_barrier per K-step, so
+//     L2 / HBM latency is covered by prefetch distance, not by occupancy;
+//   * tile shapes BM in {64,128,256} x BN in {128,160}: the host picks the shape whose grid fills the 256 CUs evenly
+//     (SD-2.1 widths are multiples of 160: 320 / 640 / 1280) - see pick_config();
+//   * LDS image is lane-linear (what the DMA writes); ds_read_b128 bank conflicts are removed by XOR-ing the 16-byte
+//     chunk index with (row>>1)&7 on the SOURCE address and on the fragment reads (same involution on both sides).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace pdmk_ring {
+
+constexpr int BK = 64, NT = 512;
+constexpr unsigned OOB = 0x80000000u;
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct ConvGeom {
+    int hi, wi, ci, ho, wo, ld, mode;
+};
+
+// source pixel of output pixel (b, oy, ox) under tap (0..8), or -1 (zero padding / zero-insertion hole / tap >= 9)
+__device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, int ox, int tap) {
+    const int ky = (tap * 11) >> 5;
+    const int kx = tap - 3 * ky;
+    const bool s2 = g.mode == 1, up = g.mode >= 2;
+    const int vy = (s2 ? 2 * oy : oy) + ky - 1, vx = (s2 ? 2 * ox : ox) + kx - 1;
+    const int hv = up ? 2 * g.hi : g.hi, wv = up ? 2 * g.wi : g.wi;
+    bool ok = (unsigned)vy < (unsigned)hv && (unsigned)vx < (unsigned)wv && tap < 9;
+    if (g.mode == 3) ok = ok && (((vy | vx) & 1) == 0);
+    const int iy = up ? (vy >> 1) : vy, ix = up ? (vx >> 1) : vx;
+    return ok ? (b * g.hi + iy) * g.wi + ix : -1;
+}
+
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform
+    switch (n) {
+#define PDMK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        PDMK_W(0) PDMK_W(1) PDMK_W(2) PDMK_W(3) PDMK_W(4) PDMK_W(5) PDMK_W(6) PDMK_W(7) PDMK_W(8) PDMK_W(9)
+        PDMK_W(10) PDMK_W(11) PDMK_W(12) PDMK_W(13) PDMK_W(14) PDMK_W(15) PDMK_W(16) PDMK_W(17) PDMK_W(18) PDMK_W(19)
+        PDMK_W(20) PDMK_W(21) PDMK_W(22) PDMK_W(23) PDMK_W(24) PDMK_W(25) PDMK_W(26) PDMK_W(27) PDMK_W(28) PDMK_W(29)
+        PDMK_W(30) PDMK_W(31) PDMK_W(32) PDMK_W(33) PDMK_W(34) PDMK_W(35) PDMK_W(36) PDMK_W(37) PDMK_W(38) PDMK_W(39)
+        PDMK_W(40) PDMK_W(41) PDMK_W(42)
+#undef PDMK_W
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // over-waits, never under-waits
+    }
+}
+
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    typedef Mma<bf16> MM;
+    constexpr int BN = 32 * NJ;
+    constexpr int IM = BM / 64;                            // 16-row MFMA tiles per wave (waves: 4 in M x 2 in N)
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLOT = A_BYTES + B_BYTES;
+    constexpr int NA = BM / 64;                            // A DMA pieces per wave and stage (8 rows x 128 B each)
+    constexpr int NBLK_B = BN / 8, NB = (NBLK_B + 7) / 8;  // B pieces: NBLK_B in all, wave w issues NBLK_B/8 + (w < NBLK_B%8)
+    static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int nk_total = (g.K + BK - 1) / BK;
+    const int per = (nk_total + gridDim.y - 1) / gridDim.y;
+    const int kt0 = blockIdx.y * per;
+    const int kt1 = min(nk_total, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
+    const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld, g.conv_mode};
+
+    // ---- loader: lane -> (sub-row sr = lane>>3 of an 8-row piece, physical 16-byte chunk pc = lane&7).  Pieces of wave w
+    // are blocks w, w+8, w+16, ... so every row this lane touches has row&15 == (w&1)*8 + sr: ONE swizzle per lane.
+    const int sr = lane >> 3;
+    const int lc = (lane & 7) ^ (((wave & 1) * 4) + (sr >> 1));      // logical chunk: k offset lc*8 inside the K-step
+    unsigned a_base[NA], b_base[NB];
+    int a_b[NA], a_oy[NA], a_ox[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        a_base[i] = OOB; a_b[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
+        const int m = m0 + (i * 8 + wave) * 8 + sr;
+        if (m < g.M) {
+            if (CONV) {
+                const int hw = cg.ho * cg.wo;
+                a_b[i] = m / hw;
+                const int rem = m - a_b[i] * hw;
+                a_oy[i] = rem / cg.wo;
+                a_ox[i] = rem - a_oy[i] * cg.wo;
+            } else {
+                a_base[i] = (unsigned)m * (unsigned)g.lda * 2u;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + (i * 8 + wave) * 8 + sr;
+        b_base[i] = (n < g.N) ? (unsigned)n * (unsigned)g.ldb * 2u : OOB;
+    }
+    const int nb_wave = NBLK_B / 8 + (wave < (NBLK_B % 8) ? 1 : 0);  // wave-uniform
+    const int ndma = NA + nb_wave;                                   // this wave's DMA instructions per stage
+    int kl = kt0 * BK + lc * 8;                                      // this lane's k of the NEXT stage to issue
+    int tap = 0, cc = 0;
+    if (CONV) {
+        tap = kl / cg.ci;
+        cc = kl - tap * cg.ci;
+    }
+
+    auto issue = [&](int slot) {
+        unsigned char* sa = smem + slot * SLOT;
+        const bool kok = kl < g.K;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            unsigned va;
+            if (CONV) {
+                const int px = a_b[i] >= 0 ? conv_src_pixel(cg, a_b[i], a_oy[i], a_ox[i], tap) : -1;
+                va = px >= 0 ? ((unsigned)px * (unsigned)cg.ld + (unsigned)cc) * 2u : OOB;
+            } else {
+                va = (a_base[i] != OOB && kok) ? a_base[i] + (unsigned)kl * 2u : OOB;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + (i * 8 + wave) * 1024), 16, (int)va, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i * 8 + wave < NBLK_B) {                             // wave-uniform
+                const unsigned vb = (b_base[i] != OOB && kok) ? b_base[i] + (unsigned)kl * 2u : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + A_BYTES + (i * 8 + wave) * 1024), 16, (int)vb, 0, 0, 0);
+            }
+        }
+        kl += BK;
+        if (CONV) {
+            cc += BK;
+            if (cc >= cg.ci) { cc -= cg.ci; ++tap; }
+            if (cc >= cg.ci) { cc -= cg.ci; ++tap; }
+        }
+    };
+
+    f32x4 acc[IM][NJ];
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: row fr = lane&15 of a 16-row MFMA tile; logical chunk kk*4 + (lane>>4) -> physical ^ ((fr>>1)&7)
+    const int fr = lane & 15;
+    const int fsw = (fr >> 1) & 7;
+    const unsigned fch0 = (unsigned)(((lane >> 4) ^ fsw) * 16), fch1 = (unsigned)(((4 + (lane >> 4)) ^ fsw) * 16);
+    const unsigned a_row = (unsigned)(wm * (16 * IM) + fr) * 128u;
+    const unsigned b_row = (unsigned)(wn * (16 * NJ) + fr) * 128u;
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (kt0 + s < kt1) issue(s);
+
+    int slot = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int ahead = min(STAGES - 2, kt1 - 1 - kt);            // younger K-steps already in flight
+        wait_vmcnt_dyn(ahead * ndma);
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
+        const unsigned char* sa = smem + slot * SLOT;
+        const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned fch = kk ? fch1 : fch0;
+            bf16x8 af[IM], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < IM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row + fch + i * 2048);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue (same contract as gemm.hip)
+    const bool first = blockIdx.y == 0;
+    const bool atomic = gridDim.y > 1;
+    const bool f32out = g.out_f32 != 0;
+    const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
+    constexpr int SROW = BN + 4;
+    constexpr int C8 = BN / 8;                                        // 8-column chunks per tile row
+    constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
+    float* stage = reinterpret_cast<float*>(smem);
+    static_assert(64 * SROW * 4 <= STAGES * SLOT, "staging image must fit the ring");
+    float* Cf = reinterpret_cast<float*>(g.C);
+    bf16* Ct = reinterpret_cast<bf16*>(g.C);
+    const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+#pragma unroll
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        __syncthreads();
+        if ((wm * 16 * IM) / 64 == pass) {
+            const int lrb = (wm * 16 * IM) % 64;
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                    *reinterpret_cast<f32x4*>(stage + (lrb + i * 16 + (lane & 15)) * SROW + wn * (16 * NJ) + j * 16 + (lane >> 4) * 4) = v;
+                }
+        }
+        if (atomic) {
+            __syncthreads();
+            for (int rr = 0; rr < 8; ++rr) {
+                const int lr2 = wave * 8 + rr, m = m0 + pass * 64 + lr2;
+                if (m >= g.M) break;
+#pragma unroll
+                for (int h = 0; h < (BN + 63) / 64; ++h) {
+                    const int cl = h * 64 + lane, n = n0 + cl;
+                    if (cl < BN && n < g.N) {
+                        float v = stage[lr2 * SROW + cl];
+                        if (first) {
+                            if (g.bias) v += g.bias[n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (Rp) v += (float)Rp[(long)m * g.ldr + n];
+                        }
+                        unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
+                    }
+                }
+            }
+        } else if (vec8) {
+            // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
+            bf16x8 rres[ITEMS], cprev[ITEMS];
+            float4 cp0[ITEMS], cp1[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                const bool ok = item < 64 * C8 && m < g.M && n < g.N;
+                const long off = (long)m * g.ldc + n;
+                if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
+                if (ok && g.accumulate) {
+                    if (f32out) { cp0[it] = *reinterpret_cast<const float4*>(Cf + off); cp1[it] = *reinterpret_cast<const float4*>(Cf + off + 4); }
+                    else cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8 + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+                if (g.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (g.rowvec) {
+                    const float* rv = g.rowvec + (long)(m / g.rows_per_b) * g.N + n;
+                    const float4 b0 = *reinterpret_cast<const float4*>(rv), b1 = *reinterpret_cast<const float4*>(rv + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (Rp) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)rres[it][r];
+                }
+                const long off = (long)m * g.ldc + n;
+                if (f32out) {
+                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                    if (g.accumulate) {
+                        o0.x += cp0[it].x; o0.y += cp0[it].y; o0.z += cp0[it].z; o0.w += cp0[it].w;
+                        o1.x += cp1[it].x; o1.y += cp1[it].y; o1.z += cp1[it].z; o1.w += cp1[it].w;
+                    }
+                    *reinterpret_cast<float4*>(Cf + off) = o0;
+                    *reinterpret_cast<float4*>(Cf + off + 4) = o1;
+                } else {
+                    if (g.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += (float)cprev[it][r];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                    *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                }
+            }
+        } else {
+            __syncthreads();
+            for (int item = tid; item < 64 * C8; item += NT) {
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+                const long off = (long)m * g.ldc + n;
+                const int nv = min(8, g.N - n);
+                for (int r = 0; r < nv; ++r) {
+                    float x = stage[lr2 * SROW + c8 * 8 + r];
+                    if (g.bias) x += g.bias[n + r];
+                    if (rv) x += rv[n + r];
+                    if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
+                    if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
+                    else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
+                }
+            }
+        }
+    }
+}
+
+struct Config {
+    int bm, nj, stages, occ;      // occ 4 = "shallow": short ring, two workgroups per CU (many-round grids, few K-steps)
+};
+// candidate table: the autotuner in gemm.hip times these per GEMM shape; ids are stable (plan cache values)
+static const Config kConfigs[] = {
+    {256, 4, 3, 2}, {256, 5, 3, 2}, {128, 4, 4, 2}, {128, 5, 4, 2}, {64, 4, 6, 2}, {64, 5, 5, 2},
+    {128, 4, 2, 4}, {64, 4, 3, 4},  {64, 5, 2, 4},  {128, 6, 3, 2}, {64, 6, 4, 2},
+};
+constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+// Untuned default (graph capture of a shape never seen eagerly, PDMK_GEMM_TUNE=0): fill the 256 CUs in as few, as
+// full rounds as possible; among equals the bigger tile.  cost = rounds x (fixed + K-steps x per-K-step time).
+static int pick_config(const pdmk_gemm_args& g, int splitk) {
+    const double nk = (double)((g.K + BK - 1) / BK) / (splitk > 1 ? splitk : 1);
+    double best = 1e30;
+    int bi = 2;
+    for (int id = 0; id < 6; ++id) {
+        const int bm = kConfigs[id].bm, bn = 32 * kConfigs[id].nj;
+        const long wgs = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (splitk > 1 ? splitk : 1);
+        const double rounds = (double)((wgs + 255) / 256);
+        const double mfma = (double)bm * bn * BK * 2 / 4096.0 / 0.80;        // cycles at 80 % of 4096 FLOP/clk/CU
+        const double feed = (double)(bm + bn) * 128.0 / 40.0;                // operand stream at ~40 B/clk/CU
+        const double kstep = mfma > feed ? mfma : feed;
+        const double fixed = 4000.0 + 22.0 * bm;                             // prologue + epilogue passes
+        const double cost = rounds * (fixed + nk * kstep);
+        if (cost < best) { best = cost; bi = id; }
+    }
+    return bi;
+}
+
+}  // namespace pdmk_ring
+
+int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs; }
+int pdmk_gemm_ring_pick(const pdmk_gemm_args& g) { return pdmk_ring::pick_config(g, g.splitk); }
+
+// called by pdmk_gemm (gemm.hip) after argument validation; returns 1 if the shape/config is not handled here
+int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
+    using namespace pdmk_ring;
+    if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
+    if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
+    if (id < 0 || id >= kNumConfigs) return 1;
+    const int sk = g.splitk > 1 ? g.splitk : 1;
+    const Config c = kConfigs[id];
+    const int bn = 32 * c.nj;
+    dim3 grid(((g.M + c.bm - 1) / c.bm) * ((g.N + bn - 1) / bn), sk);
+    const bool conv = g.a_mode == PDMK_A_CONV;
+#define PDMK_RING_GO(BMv, NJv, STv, OCv)                                                                              \
+    case (BMv * 1000 + NJv * 100 + STv * 10 + OCv):                                                                   \
+        if (conv) hipLaunchKernelGGL((igemm_ring_kernel<true, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, g,         \
+                                     (unsigned)a_bytes, (unsigned)b_bytes);                                           \
+        else hipLaunchKernelGGL((igemm_ring_kernel<false, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, g,             \
+                                (unsigned)a_bytes, (unsigned)b_bytes);                                                \
+        break;
+    switch (c.bm * 1000 + c.nj * 100 + c.stages * 10 + c.occ) {
+        PDMK_RING_GO(256, 4, 3, 2) PDMK_RING_GO(256, 5, 3, 2) PDMK_RING_GO(128, 4, 4, 2) PDMK_RING_GO(128, 5, 4, 2)
+        PDMK_RING_GO(64, 4, 6, 2) PDMK_RING_GO(64, 5, 5, 2) PDMK_RING_GO(128, 4, 2, 4) PDMK_RING_GO(64, 4, 3, 4)
+        PDMK_RING_GO(64, 5, 2, 4) PDMK_RING_GO(128, 6, 3, 2) PDMK_RING_GO(64, 6, 4, 2)
+        default: return 1;
+    }
+#undef PDMK_RING_GO
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}

@@ -45,6 +45,7 @@ class GemmArgs(C.Structure):
 _SIGS = {
     "pdmk_version": ([], i32),
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
+    "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -71,6 +72,8 @@ _SIGS = {
     "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp, vp], i32),
     "pdmk_transpose_tiles": ([vp, vp, vp, i32, i32, vp], i32),
     "pdmk_sumsq": ([vp, i64, vp, i32, vp], i32),
+    "pdmk_skinny_gemm": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_skinny_wgrad": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
     _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
@@ -134,21 +137,26 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
 
 
-def splitk_plan(M, N, K, kstep=64):
-    """Split factor for a forward/dgrad GEMM whose output grid cannot fill the chip (1 = do not split)."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    nk = K // kstep
-    # only deep-K, few-tile GEMMs (3x3 convs at 8x8 / 16x16 latents); measured: splitting 160-tile K=5120..5760 GEMMs
-    # loses to the fp32 workspace round trip, 160 tiles at K=11520 and anything below ~100 tiles wins
-    if tiles > 160 or nk < 64 or (tiles > 96 and nk < 160) or (N & 3):
-        return 1
-    return max(1, min(nk // 16, -(-512 // tiles), 16))
+def splitk_plan(A, B, M, N, K, lda, ldb, a_mode=A_ROWK, conv=None):
+    """Split-K factor for a forward/dgrad GEMM, from the library's plan cache (tuned on first sight of the shape)."""
+    g = GemmArgs()
+    g.A, g.B = _p(A), _p(B)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = lda, ldb, N
+    g.a_mode, g.b_mode = a_mode, B_ROWK
+    if conv is not None:
+        (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
+    g.dtype = dt(A)
+    g.splitk, g.alpha = 1, 1.0
+    sk = i32(1)
+    _chk(_lib.pdmk_gemm_plan(C.byref(g), _st(), C.byref(sk)), "pdmk_gemm_plan")
+    return int(sk.value)
 
 
 def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
               a_mode=A_ROWK, conv=None, accumulate=False, macs=None):
-    """Forward / dgrad GEMM with the split-K decision made here: small-M layers go through an fp32 workspace."""
-    sk = splitk_plan(M, N, K, 64 if A.dtype == torch.bfloat16 else 32)
+    """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace."""
+    sk = splitk_plan(A, B, M, N, K, lda, ldb, a_mode, conv)
     if sk == 1:
         return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
                     a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs)
@@ -232,6 +240,17 @@ def cast_permute(src, dst, n0, n1, n2, mode):
 
 def colsum(x, out, rows, N, ld, accumulate=False, nbatch=1):
     _chk(_lib.pdmk_colsum(_p(x), _p(out), rows, N, ld, int(accumulate), nbatch, dt(x), _st()), "pdmk_colsum")
+
+
+def skinny_gemm(x, w, y, M, N, K, ldx, ldw, ldy, bias=None, accumulate=False):
+    """y[M<=16, N] (+)= x @ w[N, K]^T + bias  (w in the compute dtype; x bf16/fp32; y fp32 or the compute dtype)."""
+    _chk(_lib.pdmk_skinny_gemm(_p(x), dt(x), _p(w), _p(y), _p(bias), M, N, K, ldx, ldw, ldy, dt(w),
+                               int(y.dtype == torch.float32), int(accumulate), _st()), "pdmk_skinny_gemm")
+
+
+def skinny_wgrad(dy, x, dw, dbias, M, N, K, lddy, ldx, lddw):
+    _chk(_lib.pdmk_skinny_wgrad(_p(dy), dt(dy), _p(x), _p(dw), _p(dbias), M, N, K, lddy, ldx, lddw, dt(x), _st()),
+         "pdmk_skinny_wgrad")
 
 
 def pool2x2_sum(src, dst, B, H, W, Cc):

@@ -105,10 +105,14 @@ class UNetEngine:
         M = x.t.shape[0]
         assert x.t.shape[1] == Kp, f"{key}: input has {x.t.shape[1]} cols, weight expects {Kp}"
         y = self._empty(M, Np, torch.float32 if out_f32 else None)
-        (k.gemm if out_f32 else k.gemm_auto)(
-            x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None,
-            R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
-            macs=M * e.logical[0] * e.logical[1], **({"out_f32": True} if out_f32 else {}))
+        skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * max(Kp, Np) * 4 + 512 <= 65536
+        if skinny:          # time-embedding MLP / time_emb_proj: M = batch rows -> weight-streaming kernel
+            k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None)
+        else:
+            (k.gemm if out_f32 else k.gemm_auto)(
+                x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None,
+                R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
+                macs=M * e.logical[0] * e.logical[1], **({"out_f32": True} if out_f32 else {}))
         lmacs = M * e.logical[0] * e.logical[1]
         if self.count_macs:
             self.macs += lmacs
@@ -116,6 +120,14 @@ class UNetEngine:
         if self.train:
             def bwd():
                 dy = out.g
+                if skinny:
+                    xt = x.t
+                    k.skinny_wgrad(dy, xt, P.g(key + ".weight"), P.g(bias) if bias else None, M, Np, Kp, _ld(dy),
+                                   _ld(xt), Kp)
+                    if x.rg:
+                        dx, acc = self._grad_into(x, M, Kp)
+                        k.skinny_gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc)
+                    return
                 if dy.dtype != self.dtype:        # fp32 output (time-embedding projections): tiny cast for the GEMMs
                     dyc = self._empty(M, Np)
                     k.cast_permute(dy, dyc, M * Np, 1, 1, 0)

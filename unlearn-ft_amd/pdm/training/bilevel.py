@@ -10,6 +10,8 @@ Reference arithmetic:
 """
 import math
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -147,7 +149,9 @@ class BilevelStepper:
         # the frozen teacher pass and the student forward are independent until the loss heads: they run on two HIP
         # streams (two parallel branches once captured in a hipGraph) so the small-grid layers of one fill the CUs the
         # other leaves idle
-        self.teacher_stream = torch.cuda.Stream(device=self.dev)
+        # teacher forward on its own stream (independent of the student forward); PDMK_TEACHER_STREAM=0 runs it in line
+        self.teacher_stream = (torch.cuda.Stream(device=self.dev) if os.environ.get("PDMK_TEACHER_STREAM", "1") != "0"
+                               else None)
         self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused)
 
     # ------------------------------------------------------------------ pieces
@@ -202,13 +206,14 @@ class BilevelStepper:
         ehs = self._ehs2d(prompt_embeds)
         self.losses.zero_()
         cur = torch.cuda.current_stream()
+        ts = self.teacher_stream if self.teacher_stream is not None else cur
         if need_teacher:
-            self.teacher_stream.wait_stream(cur)
-            with torch.cuda.stream(self.teacher_stream):
+            ts.wait_stream(cur)
+            with torch.cuda.stream(ts):
                 pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
         pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
         if need_teacher:
-            cur.wait_stream(self.teacher_stream)
+            cur.wait_stream(ts)
         wb = self.snr_w[timesteps].contiguous()
         HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
         k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
@@ -238,11 +243,12 @@ class BilevelStepper:
         t2 = torch.cat([timesteps, timesteps], 0)
         self.losses.zero_()
         cur = torch.cuda.current_stream()
-        self.teacher_stream.wait_stream(cur)
-        with torch.cuda.stream(self.teacher_stream):
+        ts = self.teacher_stream if self.teacher_stream is not None else cur
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
             pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
         pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
-        cur.wait_stream(self.teacher_stream)
+        cur.wait_stream(ts)
         M = B * H * W
         e_c, e_u = pred_t.t[:M], pred_t.t[M:]
         k.axpby(e_c, e_u, -1.0, 2.0)               # e_u <- 2 e_u - e_c  == e_u - (e_c - e_u)
