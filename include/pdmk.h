@@ -94,12 +94,12 @@ int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float*
  * unet_2d_conditional.py:1720-1722 and the Transformer2DModel norm (eps 1e-6).
  * x,y: [B, HW, ld]; channels [0, G*gs) are normalised in G groups of gs channels, channels [G*gs, C) (padding
  * introduced by the packed pruned layout) are written as 0.  stats: [B, G, 2] float (mean, rstd), saved for bwd.
- * ws: B*G*2 doubles of scratch (zeroed by the call).
+ * ws: B*G*64 doubles of scratch (per-block partial sums, combined in double; need not be initialised).
  */
 int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, double* ws,
                        int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps, int silu, int dtype,
                        pdmk_stream stream);
-/* dx = d(loss)/dx given dy; dgamma/dbeta (fp32 [G*gs]) are ACCUMULATED (+=).  ws: B*G*2 doubles.  part_ws: float
+/* dx = d(loss)/dx given dy; dgamma/dbeta (fp32 [G*gs]) are ACCUMULATED (+=).  ws: B*G*64 doubles.  part_ws: float
  * scratch for the two-stage per-channel reduction, part_ws_elems >= 2048 * 2 * G*gs is always enough (-1 if too small). */
 int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
                        const float* stats, float* dgamma, float* dbeta, double* ws, float* part_ws,

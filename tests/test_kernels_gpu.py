@@ -155,7 +155,8 @@ def test_conv_dgrad_via_cast_permute(dev, dn):
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
 @pytest.mark.parametrize("C,G,gs,HW,silu", [(64, 32, 2, 256, True), (40, 17, 2, 64, True), (320, 32, 10, 1024, False),
-                                            (2560, 32, 80, 64, True), (176, 17, 10, 4, True)])
+                                            (2560, 32, 80, 64, True), (176, 17, 10, 4, True), (320, 32, 10, 4096, True),
+                                            (3072, 32, 96, 16, False)])
 def test_groupnorm(dev, dn, C, G, gs, HW, silu):
     from pdm import _pdmk as k
     torch.manual_seed(5)
@@ -165,7 +166,7 @@ def test_groupnorm(dev, dn, C, G, gs, HW, silu):
     gamma, beta = torch.randn(cr, device=dev) * 0.3 + 1, torch.randn(cr, device=dev) * 0.3
     y = torch.full((Bn, HW, C), 7.0, device=dev, dtype=dt)
     stats = torch.zeros(Bn, G, 2, device=dev)
-    ws = torch.zeros(Bn * G * 2, device=dev, dtype=torch.float64)
+    ws = torch.zeros(Bn * G * 64, device=dev, dtype=torch.float64)
     k.groupnorm_fwd(x, y, gamma, beta, stats, ws, Bn, HW, C, C, C, G, gs, 1e-5, silu)
     xr = x.float()[..., :cr].permute(0, 2, 1).clone().requires_grad_(True)      # [B, cr, HW]
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)

@@ -9,16 +9,6 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAXS = 3;   // chunk slots per thread: C/chunk <= 3*256
 
-struct GnMap {
-    int tpr;   // threads per row (power of two <= 256)
-    int rif;   // rows in flight = 256 / tpr
-};
-__host__ __device__ inline GnMap gn_map(int nchunks) {
-    int tpr = 1;
-    while (tpr < nchunks && tpr < NT) tpr <<= 1;
-    return GnMap{tpr, NT / tpr};
-}
-
 // Second stage of the per-channel parameter-gradient reductions: part[b][2][n] (one slab per first-stage block, plain
 // stores) -> out0[n] += sum_b part[b][0][:], out1[n] += sum_b part[b][1][:].  Many blocks hammering the same few hundred
 // addresses with float atomics serialise at the memory side (measured 130 us for a 10 us LayerNorm backward); two
@@ -47,77 +37,139 @@ inline void launch_reduce_partials(const float* part, int nblk, int n, float* ou
                        out1);
 }
 
-// ------------------------------------------------------------------------------------------------ GroupNorm fwd
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int HW, int C,
+// ------------------------------------------------------------------------------------------------ GroupNorm
+// Thread map: a block sweeps rows [r0, r1) of one image; thread (cb, ro) owns 16-byte chunk cb (+ tpr*slot) of row
+// ro (+ rif*k).  UNR rows are loaded per iteration before any of them is used (UNR independent 16-byte loads in flight
+// per thread: these kernels are pure HBM streams, and a CU needs tens of KiB in flight to reach HBM bandwidth).
+// Reductions never use atomics: per-block partials go to a slab with plain stores and the consumer kernel's prologue
+// adds the (<= 64) slabs of its image in double (E[x^2] - mean^2 is formed in double).
+struct GnMap2 {
+    int tpr, rif;   // threads per row (= chunks per row, capped at 256), rows in flight
+};
+__host__ __device__ inline GnMap2 gn_map2(int nchunks) {
+    const int tpr = nchunks < NT ? nchunks : NT;
+    return GnMap2{tpr, NT / tpr};
+}
+constexpr int GN_MAXC = MAXS * NT * 8;   // channel capacity of the LDS reduction image (bf16 chunks)
+constexpr int GN_MAXBLK = 64;            // stats blocks per image
+
+template <typename T, int UNR, int SLOTS>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                       int ldx, int G, int gs, int rows_per_blk) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
-    const GnMap mp = gn_map(nchunks);
+    const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const bool active = ro < mp.rif;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
-    float s[MAXS][V], q[MAXS][V];
+    float s[SLOTS][V], q[SLOTS][V];
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl)
+    for (int sl = 0; sl < SLOTS; ++sl)
 #pragma unroll
         for (int e = 0; e < V; ++e) s[sl][e] = q[sl][e] = 0.f;
-    for (int r = r0 + ro; r < r1; r += mp.rif) {
-        const T* row = x + ((long)b * HW + r) * ldx;
+    if (active) {
+        for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
 #pragma unroll
-        for (int sl = 0; sl < MAXS; ++sl) {
-            const int c = cb + mp.tpr * sl;
-            if (c < nchunks) {
-                float f[V];
-                Vec<T>::load(row + c * V, f);
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = cb + mp.tpr * sl;
+                if (c < nchunks) {
+                    float f[UNR][V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) { s[sl][e] += f[e]; q[sl][e] += f[e] * f[e]; }
+                    for (int u = 0; u < UNR; ++u) {
+                        const int rr = r + u * mp.rif;
+                        if (rr < r1) Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) f[u][e] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) { s[sl][e] += f[u][e]; q[sl][e] += f[u][e] * f[u][e]; }
+                }
             }
         }
     }
-    __shared__ float ls[2][64];
-    if (tid < 128) ls[tid >> 6][tid & 63] = 0.f;
-    __syncthreads();
-    const int cr = G * gs;
+    __shared__ float red[2][GN_MAXC / 8 * V];        // [rif][C] images of the per-thread sums
+    if (active) {
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl) {
-        const int c = cb + mp.tpr * sl;
-        if (c < nchunks) {
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int ch = c * V + e;
-                if (ch < cr) {
-                    const int g = ch / gs;
-                    atomicAdd(&ls[0][g], s[sl][e]);
-                    atomicAdd(&ls[1][g], q[sl][e]);
+                for (int e = 0; e < V; ++e) {
+                    red[0][ro * C + c * V + e] = s[sl][e];
+                    red[1][ro * C + c * V + e] = q[sl][e];
                 }
             }
         }
     }
     __syncthreads();
+    // 256 threads: (group g = tid % 64, quarter = tid / 64) -> partial over a quarter of the group's (row, channel) cells
+    const int g = tid & 63, qt = tid >> 6;
+    float ps = 0.f, pq = 0.f;
+    if (g < G) {
+        const int cells = mp.rif * gs;
+        for (int i = qt; i < cells; i += 4) {
+            const int rr = i / gs, ch = g * gs + (i - rr * gs);
+            ps += red[0][rr * C + ch];
+            pq += red[1][rr * C + ch];
+        }
+    }
+    __syncthreads();
+    red[0][tid] = ps;
+    red[1][tid] = pq;
+    __syncthreads();
     if (tid < G) {
-        atomicAdd(&ws[((long)b * G + tid) * 2 + 0], (double)ls[0][tid]);
-        atomicAdd(&ws[((long)b * G + tid) * 2 + 1], (double)ls[1][tid]);
+        float* slab = part + (((long)b * gridDim.x + blockIdx.x) * G + tid) * 2;
+        slab[0] = (red[0][tid] + red[0][tid + 64]) + (red[0][tid + 128] + red[0][tid + 192]);
+        slab[1] = (red[1][tid] + red[1][tid + 64]) + (red[1][tid + 128] + red[1][tid + 192]);
     }
 }
 
-template <typename T>
+// sums the nblk per-block (sum0, sum1) slabs of image b into LDS out0[g], out1[g] (double); all 256 threads take part
+__device__ __forceinline__ void gn_sum_slabs(const float* __restrict__ part, int b, int nblk, int G, double* out0,
+                                             double* out1, double (*scr)[NT]) {
+    const int tid = threadIdx.x, g = tid & 63, qt = tid >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    if (g < G)
+        for (int k = qt; k < nblk; k += 4) {
+            const float* slab = part + (((long)b * nblk + k) * G + g) * 2;
+            a0 += (double)slab[0];
+            a1 += (double)slab[1];
+        }
+    scr[0][tid] = a0;
+    scr[1][tid] = a1;
+    __syncthreads();
+    if (tid < G) {
+        out0[tid] = (scr[0][tid] + scr[0][tid + 64]) + (scr[0][tid + 128] + scr[0][tid + 192]);
+        out1[tid] = (scr[1][tid] + scr[1][tid + 64]) + (scr[1][tid + 128] + scr[1][tid + 192]);
+    }
+    __syncthreads();
+}
+
+template <typename T, int UNR, int SLOTS>
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const double* __restrict__ ws, float* __restrict__ stats, int HW,
+                                                      const float* __restrict__ part, int nblk,
+                                                      float* __restrict__ stats, int HW,
                                                       int C, int ldx, int ldy, int G, int gs, float eps, int silu,
                                                       int rows_per_blk) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
-    const GnMap mp = gn_map(nchunks);
+    const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    __shared__ double scr[2][NT], d0[64], d1[64];
     __shared__ float lm[64], lr[64];
+    gn_sum_slabs(part, b, nblk, G, d0, d1, scr);
     if (tid < G) {
         const double n = (double)HW * gs;
-        const double mean = ws[((long)b * G + tid) * 2] / n;
-        double var = ws[((long)b * G + tid) * 2 + 1] / n - mean * mean;
+        const double mean = d0[tid] / n;
+        double var = d1[tid] / n - mean * mean;
         if (var < 0) var = 0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         lm[tid] = (float)mean;
@@ -128,10 +180,11 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
         }
     }
     __syncthreads();
+    if (ro >= mp.rif) return;
     const int cr = G * gs;
-    float sc[MAXS][V], sh[MAXS][V];   // y = x*sc + sh  (pad channels: 0)
+    float sc[SLOTS][V], sh[SLOTS][V];   // y = x*sc + sh  (pad channels: 0)
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -145,47 +198,56 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
             }
         }
     }
-    for (int r = r0 + ro; r < r1; r += mp.rif) {
-        const T* row = x + ((long)b * HW + r) * ldx;
-        T* orow = y + ((long)b * HW + r) * ldy;
+    for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
 #pragma unroll
-        for (int sl = 0; sl < MAXS; ++sl) {
+        for (int sl = 0; sl < SLOTS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[V];
-                Vec<T>::load(row + c * V, f);
+                float f[UNR][V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    float z = f[e] * sc[sl][e] + sh[sl][e];
-                    f[e] = silu ? silu_f(z) : z;
+                for (int u = 0; u < UNR; ++u) {
+                    const int rr = r + u * mp.rif;
+                    if (rr < r1) Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
                 }
-                Vec<T>::store(orow + c * V, f);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int rr = r + u * mp.rif;
+                    if (rr < r1) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float z = f[u][e] * sc[sl][e] + sh[sl][e];
+                            f[u][e] = silu ? silu_f(z) : z;
+                        }
+                        Vec<T>::store(y + ((long)b * HW + rr) * ldy + c * V, f[u]);
+                    }
+                }
             }
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------ GroupNorm bwd
-// pass 1: per (b,g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat ; per channel dgamma += sum dz*xhat, dbeta += sum dz
-template <typename T>
+// backward pass 1: per (b,g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat (slab `gpart`); per channel dgamma += sum
+// dz*xhat, dbeta += sum dz (slab `part`, second stage reduce_partials_kernel)
+template <typename T, int UNR, int SLOTS>
 __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ stats, float* __restrict__ part,
-                                                          double* __restrict__ ws, int HW,
+                                                          float* __restrict__ gpart, int HW,
                                                           int C, int ldx, int lddy, int G, int gs, int silu,
                                                           int rows_per_blk) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
-    const GnMap mp = gn_map(nchunks);
+    const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
+    const bool active = ro < mp.rif;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
     const int cr = G * gs;
-    float mean[MAXS][V], rstd[MAXS][V], gm[MAXS][V], bt[MAXS][V];
-    float a1[MAXS][V], a2[MAXS][V];
+    float mean[SLOTS][V], rstd[SLOTS][V], gm[SLOTS][V], bt[SLOTS][V];
+    float a1[SLOTS][V], a2[SLOTS][V];
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -201,95 +263,102 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ 
             }
         }
     }
-    for (int r = r0 + ro; r < r1; r += 2 * mp.rif) {      // two rows per iteration: 4 independent loads per slot
-        const bool two = r + mp.rif < r1;
-        const T* row = x + ((long)b * HW + r) * ldx;
-        const T* drow = dy + ((long)b * HW + r) * lddy;
-        const T* row2 = two ? row + (long)mp.rif * ldx : row;
-        const T* drow2 = two ? drow + (long)mp.rif * lddy : drow;
+    if (active) {
+        for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
 #pragma unroll
-        for (int sl = 0; sl < MAXS; ++sl) {
-            const int c = cb + mp.tpr * sl;
-            if (c < nchunks) {
-                float f[V], d[V], f2[V], d2[V];
-                Vec<T>::load(row + c * V, f);
-                Vec<T>::load(drow + c * V, d);
-                Vec<T>::load(row2 + c * V, f2);
-                Vec<T>::load(drow2 + c * V, d2);
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = cb + mp.tpr * sl;
+                if (c < nchunks) {
+                    float f[UNR][V], d[UNR][V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
-                    float dz = d[e];
-                    if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
-                    a1[sl][e] += dz;
-                    a2[sl][e] += dz * xh;
-                    const float xh2 = (f2[e] - mean[sl][e]) * rstd[sl][e];
-                    float dz2 = two ? d2[e] : 0.f;
-                    if (silu) dz2 *= silu_grad_f(xh2 * gm[sl][e] + bt[sl][e]);
-                    a1[sl][e] += dz2;
-                    a2[sl][e] += dz2 * xh2;
+                    for (int u = 0; u < UNR; ++u) {
+                        const int rr = r + u * mp.rif;
+                        if (rr < r1) {
+                            Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
+                            Vec<T>::load(dy + ((long)b * HW + rr) * lddy + c * V, d[u]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < V; ++e) f[u][e] = d[u][e] = 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float xh = (f[u][e] - mean[sl][e]) * rstd[sl][e];
+                            float dz = d[u][e];
+                            if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
+                            a1[sl][e] += dz;
+                            a2[sl][e] += dz * xh;
+                        }
                 }
             }
         }
     }
-    __shared__ float ls[2][64];
-    __shared__ float red[2][NT * V];
-    if (tid < 128) ls[tid >> 6][tid & 63] = 0.f;
+    __shared__ float red[2][GN_MAXC / 8 * V];        // [rif][C] images of the per-thread sums
+    if (active) {
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl) {
-        const int c = cb + mp.tpr * sl;
-        // combine the rows-in-flight of this block in LDS: one global atomic per channel per block
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < V; ++e) { red[0][tid * V + e] = a1[sl][e]; red[1][tid * V + e] = a2[sl][e]; }
-        __syncthreads();
-        if (ro == 0 && c < nchunks) {
-            for (int j = 1; j < mp.rif; ++j)
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+            if (c < nchunks) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    a1[sl][e] += red[0][(j * mp.tpr + cb) * V + e];
-                    a2[sl][e] += red[1][(j * mp.tpr + cb) * V + e];
-                }
-#pragma unroll
-            for (int e = 0; e < V; ++e) {
-                const int ch = c * V + e;
-                if (ch < cr) {
-                    const int g = ch / gs;
-                    atomicAdd(&ls[0][g], gm[sl][e] * a1[sl][e]);
-                    atomicAdd(&ls[1][g], gm[sl][e] * a2[sl][e]);
-                    float* slab = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * cr;   // [dgamma | dbeta]
-                    slab[ch] = a2[sl][e];
-                    slab[cr + ch] = a1[sl][e];
+                    red[0][ro * C + c * V + e] = a1[sl][e];
+                    red[1][ro * C + c * V + e] = a2[sl][e];
                 }
             }
         }
     }
     __syncthreads();
+    // per-channel sums over the rows in flight -> row 0 of the image (+ the dgamma/dbeta slab of this block)
+    float* slab = part + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * cr;                 // [dgamma | dbeta]
+    for (int ch = tid; ch < cr; ch += NT) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int rr = 0; rr < mp.rif; ++rr) { t1 += red[0][rr * C + ch]; t2 += red[1][rr * C + ch]; }
+        slab[ch] = t2;
+        slab[cr + ch] = t1;
+        const float gmc = gamma[ch];
+        red[0][ch] = gmc * t1;      // only row 0 is read below; rows >= 1 of other channels are not touched by this thread
+        red[1][ch] = gmc * t2;
+    }
+    __syncthreads();
+    const int g = tid & 63, qt = tid >> 6;
+    float ps = 0.f, pq = 0.f;
+    if (g < G)
+        for (int i = qt; i < gs; i += 4) { ps += red[0][g * gs + i]; pq += red[1][g * gs + i]; }
+    __syncthreads();
+    red[0][tid] = ps;
+    red[1][tid] = pq;
+    __syncthreads();
     if (tid < G) {
-        atomicAdd(&ws[((long)b * G + tid) * 2 + 0], (double)ls[0][tid]);
-        atomicAdd(&ws[((long)b * G + tid) * 2 + 1], (double)ls[1][tid]);
+        float* gs_ = gpart + (((long)b * gridDim.x + blockIdx.x) * G + tid) * 2;
+        gs_[0] = (red[0][tid] + red[0][tid + 64]) + (red[0][tid + 128] + red[0][tid + 192]);
+        gs_[1] = (red[1][tid] + red[1][tid + 64]) + (red[1][tid + 128] + red[1][tid + 192]);
     }
 }
 
-template <typename T>
+template <typename T, int UNR, int SLOTS>
 __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                           T* __restrict__ dx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ stats,
-                                                          const double* __restrict__ ws, int HW, int C, int ldx,
-                                                          int lddy, int lddx, int G, int gs, int silu, int accumulate,
-                                                          int rows_per_blk) {
+                                                          const float* __restrict__ gpart, int nblk, int HW, int C,
+                                                          int ldx, int lddy, int lddx, int G, int gs, int silu,
+                                                          int accumulate, int rows_per_blk) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
-    const GnMap mp = gn_map(nchunks);
+    const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
     const int cr = G * gs;
-    const float invn = 1.0f / ((float)HW * gs);
-    float mean[MAXS][V], rstd[MAXS][V], gm[MAXS][V], bt[MAXS][V], c1[MAXS][V], c2[MAXS][V];
+    __shared__ double scr[2][NT], d0[64], d1[64];
+    gn_sum_slabs(gpart, b, nblk, G, d0, d1, scr);
+    if (ro >= mp.rif) return;
+    const double invn = 1.0 / ((double)HW * gs);
+    float mean[SLOTS][V], rstd[SLOTS][V], gm[SLOTS][V], bt[SLOTS][V], c1[SLOTS][V], c2[SLOTS][V];
 #pragma unroll
-    for (int sl = 0; sl < MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -301,55 +370,76 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                 rstd[sl][e] = stats[((long)b * G + g) * 2 + 1];
                 gm[sl][e] = gamma[ch];
                 bt[sl][e] = beta[ch];
-                c1[sl][e] = (float)(ws[((long)b * G + g) * 2] * invn);
-                c2[sl][e] = (float)(ws[((long)b * G + g) * 2 + 1] * invn);
+                c1[sl][e] = (float)(d0[g] * invn);
+                c2[sl][e] = (float)(d1[g] * invn);
             }
         }
     }
-    for (int r = r0 + ro; r < r1; r += mp.rif) {
-        const T* row = x + ((long)b * HW + r) * ldx;
-        const T* drow = dy + ((long)b * HW + r) * lddy;
-        T* orow = dx + ((long)b * HW + r) * lddx;
+    for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
 #pragma unroll
-        for (int sl = 0; sl < MAXS; ++sl) {
+        for (int sl = 0; sl < SLOTS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[V], d[V], o[V];
-                Vec<T>::load(row + c * V, f);
-                Vec<T>::load(drow + c * V, d);
-                if (accumulate) Vec<T>::load(orow + c * V, o);
+                float f[UNR][V], d[UNR][V], o[UNR][V];
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
-                    float dz = d[e];
-                    if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
-                    const float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
-                    o[e] = accumulate ? o[e] + v : v;
+                for (int u = 0; u < UNR; ++u) {
+                    const int rr = r + u * mp.rif;
+                    if (rr < r1) {
+                        Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
+                        Vec<T>::load(dy + ((long)b * HW + rr) * lddy + c * V, d[u]);
+                        if (accumulate) Vec<T>::load(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
+                    }
                 }
-                Vec<T>::store(orow + c * V, o);
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int rr = r + u * mp.rif;
+                    if (rr < r1) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) {
+                            const float xh = (f[u][e] - mean[sl][e]) * rstd[sl][e];
+                            float dz = d[u][e];
+                            if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
+                            const float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
+                            o[u][e] = accumulate ? o[u][e] + v : v;
+                        }
+                        Vec<T>::store(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
+                    }
+                }
             }
         }
     }
 }
 
-inline int gn_rows_per_blk(int B, int HW, int rif, int target_blocks = 1024) {
-    // aim for ~target_blocks blocks chip-wide, at least one sweep of rows-in-flight per block
-    int nchunk = max(1, min(HW / max(1, rif), (target_blocks + B - 1) / B));
-    return (HW + nchunk - 1) / nchunk;
+// rows per block for ~target_blocks blocks chip-wide (at most max_blk per image, at least one sweep of rows per block)
+inline int gn_rows_per_blk(int B, int HW, int sweep, int target_blocks, int max_blk) {
+    int nb = (target_blocks + B - 1) / B;
+    nb = max(1, min(min(nb, max_blk), HW / max(1, sweep)));
+    return (HW + nb - 1) / nb;
 }
 
 template <typename T>
 int gn_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, double* ws, int B, int HW,
            int C, int ldx, int ldy, int G, int gs, float eps, int silu, hipStream_t st) {
     constexpr int V = Vec<T>::N;
-    if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
-    const GnMap mp = gn_map(C / V);
-    const int rpb = gn_rows_per_blk(B, HW, mp.rif);
+    if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT || C > GN_MAXC / 8 * V) return -1;
+    const GnMap2 mp = gn_map2(C / V);
+    float* part = reinterpret_cast<float*>(ws);                     // [B][nblk][G][2] floats <= B*G*64 doubles
+    const int rpb_s = gn_rows_per_blk(B, HW, mp.rif * 8, 512, GN_MAXBLK);
+    dim3 grid_s((HW + rpb_s - 1) / rpb_s, B);
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif * 4, 1024, 1 << 20);
     dim3 grid((HW + rpb - 1) / rpb, B);
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) return -1000;
-    hipLaunchKernelGGL(gn_stats_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, ws, HW, C, ldx, G, gs, rpb);
-    hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, ws, stats, HW, C,
-                       ldx, ldy, G, gs, eps, silu, rpb);
+    const int slots = (C / V + NT - 1) / NT;
+#define PDMK_GNF(S)                                                                                                   \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((gn_stats_kernel<T, 8, S>), grid_s, dim3(NT), 0, st, (const T*)x, part, HW, C, ldx, G, gs, \
+                           rpb_s);                                                                                    \
+        hipLaunchKernelGGL((gn_apply_kernel<T, 4, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, part,  \
+                           (int)grid_s.x, stats, HW, C, ldx, ldy, G, gs, eps, silu, rpb);                             \
+    } while (0)
+    if (slots == 1) PDMK_GNF(1);
+    else if (slots == 2) PDMK_GNF(2);
+    else PDMK_GNF(3);
+#undef PDMK_GNF
     PDMK_CHECK_LAUNCH();
     return 0;
 }
@@ -359,20 +449,28 @@ int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
            float* dgamma, float* dbeta, double* ws, float* part, long part_elems, int B, int HW, int C, int ldx,
            int lddy, int lddx, int G, int gs, int silu, int acc, hipStream_t st) {
     constexpr int V = Vec<T>::N;
-    if (C % V || ldx % V || lddy % V || lddx % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
-    const GnMap mp = gn_map(C / V);
-    const int rpb_s = gn_rows_per_blk(B, HW, mp.rif, 1024);
+    if (C % V || ldx % V || lddy % V || lddx % V || G > 64 || G * gs > C || C / V > MAXS * NT || C > GN_MAXC / 8 * V) return -1;
+    const GnMap2 mp = gn_map2(C / V);
+    const int rpb_s = gn_rows_per_blk(B, HW, mp.rif * 4, 512, GN_MAXBLK);
     dim3 grid_s((HW + rpb_s - 1) / rpb_s, B);
     const int nblk = grid_s.x * grid_s.y, cr = G * gs;
     if (!part || (long)nblk * 2 * cr > part_elems) return -1;
-    const int rpb = gn_rows_per_blk(B, HW, mp.rif);
+    float* gpart = reinterpret_cast<float*>(ws);                    // [B][nblk][G][2] floats <= B*G*64 doubles
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif * 2, 1024, 1 << 20);
     dim3 grid((HW + rpb - 1) / rpb, B);
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) return -1000;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, grid_s, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
-                       part, ws, HW, C, ldx, lddy, G, gs, silu, rpb_s);
-    launch_reduce_partials(part, nblk, cr, dgamma, dbeta, st);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, (T*)dx, gamma, beta,
-                       stats, ws, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb);
+    const int slots = (C / V + NT - 1) / NT;
+#define PDMK_GNB(S)                                                                                                   \
+    do {                                                                                                              \
+        hipLaunchKernelGGL((gn_bwd_stats_kernel<T, 4, S>), grid_s, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, \
+                           beta, stats, part, gpart, HW, C, ldx, lddy, G, gs, silu, rpb_s);                           \
+        launch_reduce_partials(part, nblk, cr, dgamma, dbeta, st);                                                    \
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 2, S>), grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, (T*)dx,  \
+                           gamma, beta, stats, gpart, (int)grid_s.x, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb);  \
+    } while (0)
+    if (slots == 1) PDMK_GNB(1);
+    else if (slots == 2) PDMK_GNB(2);
+    else PDMK_GNB(3);
+#undef PDMK_GNB
     PDMK_CHECK_LAUNCH();
     return 0;
 }

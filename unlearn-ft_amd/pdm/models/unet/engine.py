@@ -36,7 +36,7 @@ class UNetEngine:
         half = cfg.block_out_channels[0] // 2
         # frequency table of Timesteps(dim, flip_sin_to_cos=True, shift=0): built exactly like the reference (fp32 exp)
         self.freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(self.dev)
-        self.ws = torch.zeros(64 * 64 * 2, device=self.dev, dtype=torch.float64)   # GN scratch: B*G*2 doubles
+        self.ws = torch.zeros(1 << 17, device=self.dev, dtype=torch.float64)   # GN scratch: >= B*G*64 doubles
         self.tape = []
         self.train = False
         self.macs = 0
