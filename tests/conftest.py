@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("PDMK_ENV_DYNAMIC", "1")     # lets tests force GEMM candidates through PDMK_RING_CFG / PDMK_WGRAD_CFG
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "unlearn-ft_amd"), os.path.join(ROOT, "oracle"), ROOT):
     if p not in sys.path:

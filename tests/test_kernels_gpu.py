@@ -400,3 +400,87 @@ def test_skinny_gemm_and_wgrad(dev, dn, M, N, K):
         k.skinny_wgrad(dy, x, dw, db, M, N, K, N, K, K)
         close(dw, 1.0 + dy.float().t() @ x.float(), TOL[dn], "skinny wgrad")
         close(db, 1.0 + dy.float().sum(0), TOL[dn], "skinny bias grad")
+
+
+@pytest.fixture
+def force_cfg():
+    """Force a GEMM candidate (0 = K-step-32 kernels, 1.. = LDS-DMA ring shapes) instead of the tuned plan."""
+    import os
+    def setter(var, val):
+        os.environ[var] = str(val)
+    yield setter
+    for var in ("PDMK_RING_CFG", "PDMK_WGRAD_CFG"):
+        os.environ.pop(var, None)
+
+
+@pytest.mark.parametrize("cand", list(range(12)))
+def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
+    """Every fwd/dgrad candidate of the plan cache gives the same linear + 3x3-conv results (ragged M/N/K tails, K not
+    a multiple of the K-step, stride-2 / upsample / transposed gathers, split-K with fp32 atomics)."""
+    from pdm import _pdmk as k
+    force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(7)
+    dt = torch.bfloat16
+    for M, N, K in ((515, 352, 608), (200, 136, 96), (64, 32, 32), (1000, 1280, 160)):
+        A, B = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5)
+        bias, R = torch.randn(N, device=dev), rnd((M, N), dev, dt)
+        C = torch.full((M, N), 3.0, device=dev, dtype=dt)
+        k.gemm(A, B, C, M, N, K, K, K, N, bias=bias, R=R, ldr=N)
+        ref = A.float() @ B.float().t() + bias + R.float()
+        close(C, ref, 2e-2, f"linear {M}x{N}x{K}")
+        Cf = torch.zeros(M, N, device=dev)
+        k.gemm(A, B, Cf, M, N, K, K, K, N, out_f32=True, splitk=3)
+        close(Cf, A.float() @ B.float().t(), 2e-2, f"linear split-K {M}x{N}x{K}")
+    Bn, Ci, Co, Hs = 2, 96, 72, 12
+    x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+    w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
+    xn = x.float().permute(0, 3, 1, 2)
+    for mode in (0, 1, 2):
+        if mode == 0:
+            ref = F.conv2d(xn, w.float(), padding=1)
+        elif mode == 1:
+            ref = F.conv2d(xn, w.float(), stride=2, padding=1)
+        else:
+            ref = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode="nearest"), w.float(), padding=1)
+        Ho = ref.shape[2]
+        y = torch.zeros(Bn * Ho * Ho, Co, device=dev, dtype=dt)
+        k.gemm(x, conv_w_pack(w), y, Bn * Ho * Ho, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV,
+               conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci))
+        close(y, ref.permute(0, 2, 3, 1).reshape(-1, Co), 2e-2, f"conv mode {mode}")
+
+
+@pytest.mark.parametrize("cand", [0, 1, 2])
+def test_ring_wgrad_candidates(dev, force_cfg, cand):
+    from pdm import _pdmk as k
+    force_cfg("PDMK_WGRAD_CFG", cand)
+    torch.manual_seed(8)
+    dt = torch.bfloat16
+    for P, No, Ki, sk in ((300, 96, 160, 1), (4096, 320, 352, 5), (1000, 160, 288, 2)):
+        dY, X = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
+        dW = torch.ones(No, Ki, device=dev)
+        db = torch.ones(No, device=dev)
+        k.gemm(dY, X, dW, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
+               accumulate=(sk == 1), colsum_out=db)
+        close(dW, 1.0 + dY.float().t() @ X.float(), 2e-2, f"wgrad linear P{P}")
+        close(db, 1.0 + dY.float().sum(0), 2e-2, "fused bias gradient")
+    Bn, Ci, Co, Hs = 2, 96, 160, 12
+    x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+    xn = x.float().permute(0, 3, 1, 2)
+    for mode in (0, 1, 2):
+        w = torch.zeros(Co, Ci, 3, 3, device=dev, requires_grad=True)
+        if mode == 0:
+            y = F.conv2d(xn, w, padding=1)
+        elif mode == 1:
+            y = F.conv2d(xn, w, stride=2, padding=1)
+        else:
+            y = F.conv2d(F.interpolate(xn, scale_factor=2.0, mode="nearest"), w, padding=1)
+        Ho = y.shape[2]
+        dy = rnd((Bn, Ho, Ho, Co), dev, dt)
+        (gw,) = torch.autograd.grad(y, w, dy.float().permute(0, 3, 1, 2))
+        P = Bn * Ho * Ho
+        dW = torch.zeros(Co, 9 * Ci, device=dev)
+        db = torch.zeros(Co, device=dev)
+        k.gemm(dy, x, dW, Co, 9 * Ci, P, Co, 0, 9 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=2,
+               conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci), colsum_out=db)
+        close(dW, conv_w_pack(gw), 2e-2, f"wgrad conv mode {mode}")
+        close(db, dy.float().sum(dim=(0, 1, 2)), 2e-2, "fused conv bias gradient")

@@ -130,9 +130,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// SiLU with the hardware exponential / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each, far inside the bf16 and the 1e-3
+// fp32 tolerances); the libm expf + IEEE division cost ~10x the instructions and made GroupNorm+SiLU VALU-bound.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
-    const float s = 1.0f / (1.0f + expf(-x));
+    const float s = sigmoid_fast(x);
     return s * (1.0f + x * (1.0f - s));
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -477,6 +477,8 @@ int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, 
 int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id);  // gemm_ring.hip
 int pdmk_gemm_ring_num_configs();
 int pdmk_gemm_ring_pick(const pdmk_gemm_args& g);
+int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id);
+int pdmk_wgrad_ring_num_configs();
 
 static int env_int(const char* name, int def, int* cache) {     // cached unless PDMK_ENV_DYNAMIC is set (A/B tools)
     static int dynamic = -1;
@@ -491,6 +493,7 @@ static int dma_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_DMA"
 static int ring_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_RING", 1, &c); }  // 0: K-step-32 kernels only
 static int tune_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_TUNE", 1, &c); }  // 0: heuristics only
 static int forced_cfg() { static int c = INT32_MIN; return env_int("PDMK_RING_CFG", -1, &c); } // >= 0: that candidate id
+static int forced_wcfg() { static int c = INT32_MIN; return env_int("PDMK_WGRAD_CFG", -1, &c); } // same, weight gradients
 
 // ---------------------------------------------------------------------------------------------------------------
 // Plan cache.  The forward / dgrad GEMMs of the step come in ~200 shapes whose best tile shape, ring depth and split-K
@@ -501,7 +504,7 @@ static int forced_cfg() { static int c = INT32_MIN; return env_int("PDMK_RING_CF
 namespace {
 
 struct PlanKey {
-    int v[9];
+    int v[10];
     bool operator<(const PlanKey& o) const { return memcmp(v, o.v, sizeof v) < 0; }
 };
 std::mutex g_plan_mu;
@@ -512,9 +515,9 @@ size_t g_scratch_bytes = 0;
 
 PlanKey make_key(const pdmk_gemm_args& g, int sk) {
     PlanKey k;
-    const bool cv = g.a_mode == PDMK_A_CONV;
-    const int v[9] = {g.M, g.N, g.K, g.a_mode, cv ? g.conv_mode : 0, cv ? g.conv_hi : 0, cv ? g.conv_wi : 0,
-                      cv ? g.conv_ci : 0, sk};
+    const bool cv = g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV;
+    const int v[10] = {g.M, g.N, g.K, g.a_mode, g.b_mode, cv ? g.conv_mode : 0, cv ? g.conv_hi : 0, cv ? g.conv_wi : 0,
+                       cv ? g.conv_ci : 0, sk};
     memcpy(k.v, v, sizeof v);
     return k;
 }
@@ -523,10 +526,17 @@ bool ring_eligible(const pdmk_gemm_args& g) {
     return g.dtype == PDMK_BF16 && g.b_mode == PDMK_B_ROWK && g.a_mode != PDMK_A_COLK;
 }
 
+bool wgrad_eligible(const pdmk_gemm_args& g) {
+    return g.dtype == PDMK_BF16 && g.a_mode == PDMK_A_COLK && g.b_mode != PDMK_B_ROWK && g.out_f32 &&
+           (g.b_mode == PDMK_B_COLK || g.conv_mode <= 2);
+}
+
 bool operand_bytes(const pdmk_gemm_args& g, long* ab, long* bb) {
     const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * 2;
-    *ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2 : conv_bytes;
-    *bb = ((long)(g.N - 1) * g.ldb + g.K) * 2;
+    *ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2
+        : g.a_mode == PDMK_A_CONV ? conv_bytes : ((long)(g.K - 1) * g.lda + g.M) * 2;
+    *bb = g.b_mode == PDMK_B_ROWK ? ((long)(g.N - 1) * g.ldb + g.K) * 2
+        : g.b_mode == PDMK_B_COLK ? ((long)(g.K - 1) * g.ldb + g.N) * 2 : conv_bytes;
     return *ab < (1L << 31) && *bb < (1L << 31);
 }
 
@@ -544,6 +554,7 @@ int launch_candidate(const pdmk_gemm_args& g, hipStream_t st, int id) {
     if (id <= 0) return launch_legacy(g, st);
     long ab, bb;
     if (!operand_bytes(g, &ab, &bb)) return 1;
+    if (g.a_mode == PDMK_A_COLK) return pdmk_wgrad_ring_launch(g, st, ab, bb, id - 1);
     return pdmk_gemm_ring_launch(g, st, ab, bb, id - 1);
 }
 
@@ -568,7 +579,7 @@ bool ensure_scratch(size_t bytes) {
 float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws, void* fin_out, hipEvent_t e0, hipEvent_t e1) {
     const int reps = 3;
     auto once = [&]() -> int {
-        if (a.splitk > 1) {
+        if (a.splitk > 1 && a.a_mode != PDMK_A_COLK) {
             if (hipMemsetAsync(ws, 0, (size_t)a.M * a.N * 4, st) != hipSuccess) return -1;
             const int rc = launch_candidate(a, st, id);
             if (rc) return rc;
@@ -590,7 +601,7 @@ float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws,
 // best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().
 int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     const size_t out_bytes = (size_t)g.M * g.N * 4;
-    if (!ensure_scratch(2 * out_bytes + 256)) return -1;
+    if (!ensure_scratch(2 * out_bytes + (size_t)g.M * 4 + 256)) return -1;
     (void)hipDeviceSynchronize();                    // other streams (teacher branch) must not overlap the timings
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
@@ -600,11 +611,14 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     a.accumulate = 0;
     a.splitk = sk;
     a.ldc = g.N;
-    if (sk > 1) { a.C = ws; a.out_f32 = 1; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
+    if (g.a_mode == PDMK_A_COLK) {           // wgrad: fp32 output, atomics for sk > 1, bias gradient into scratch
+        a.C = ws;
+        if (a.colsum_out) a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(g_scratch) + 2 * out_bytes);
+    } else if (sk > 1) { a.C = ws; a.out_f32 = 1; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
     else a.C = out2;
     int best = -1;
     float bt = 1e30f;
-    const int ncand = 1 + pdmk_gemm_ring_num_configs();
+    const int ncand = 1 + (g.a_mode == PDMK_A_COLK ? pdmk_wgrad_ring_num_configs() : pdmk_gemm_ring_num_configs());
     for (int id = 0; id < ncand; ++id) {
         const float t = time_candidate(a, st, id, ws, out2, e0, e1);
         if (t < bt) { bt = t; best = id; }
@@ -620,7 +634,17 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
 
 int heuristic_cfg(const pdmk_gemm_args& g) {
     if (!ring_mode()) return 0;
+    if (g.a_mode == PDMK_A_COLK) return 1;
     return 1 + pdmk_gemm_ring_pick(g);
+}
+
+int heuristic_wgrad_sk(const pdmk_gemm_args& g) {     // untuned default: ~512 workgroups, >= 16 K-steps per split
+    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int nk = g.K / 64 > 0 ? g.K / 64 : 1;
+    int s = 512 / (tiles > 0 ? tiles : 1);
+    if (s > nk / 16) s = nk / 16;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
 }
 
 int heuristic_sk(const pdmk_gemm_args& g) {           // untuned default: only deep-K, few-tile GEMMs are split
@@ -662,8 +686,11 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.splitk > 1 && !(g.out_f32 || g.dtype == PDMK_F32)) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (!ring_eligible(g) || (g.K % 8)) return launch_legacy(g, st);
-    if (forced_cfg() >= 0) return launch_candidate(g, st, forced_cfg());
+    if (!(ring_eligible(g) && (g.K % 8) == 0) && !wgrad_eligible(g)) return launch_legacy(g, st);
+    if (g.a_mode == PDMK_A_COLK ? forced_wcfg() >= 0 : forced_cfg() >= 0) {
+        const int rc = launch_candidate(g, st, g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
+        return rc == 1 ? launch_legacy(g, st) : rc;
+    }
     const int sk = g.splitk > 1 ? g.splitk : 1;
     int id;
     {
@@ -690,7 +717,12 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     *splitk_out = 1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
     if (g.N & 3) return 0;
-    if (!ring_eligible(g) || (g.K % 8) || forced_cfg() >= 0) {
+    const bool wg = wgrad_eligible(g);
+    if (g.a_mode == PDMK_A_COLK && !wg) {
+        *splitk_out = heuristic_wgrad_sk(g);
+        return 0;
+    }
+    if (!wg && (!ring_eligible(g) || (g.K % 8) || forced_cfg() >= 0)) {
         *splitk_out = heuristic_sk(g);
         return 0;
     }
@@ -698,15 +730,18 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     const PlanKey key0 = make_key(g, 0);
     auto it = g_plan_sk.find(key0);
     if (it != g_plan_sk.end()) { *splitk_out = it->second; return 0; }
-    if (!can_tune(st) || !a->A || !a->B) { *splitk_out = heuristic_sk(g); return 0; }
+    if (!can_tune(st) || !a->A || !a->B) { *splitk_out = wg ? heuristic_wgrad_sk(g) : heuristic_sk(g); return 0; }
     const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int nk = (g.K + 63) / 64;
-    const int cands[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    const int cands[12] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     int best_sk = 1;
     float bt = 1e30f;
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 12; ++c) {
         const int sk = cands[c];
-        if (sk > 1 && (tiles > 200 || nk < 24 || nk / sk < 6 || (long)tiles * sk > 768)) continue;
+        if (wg) {      // weight gradients: the reduction (pixels) is the long dimension, the output is small
+            if (sk > 1 && (nk / sk < 4 || (long)tiles * sk > 1280)) continue;
+            if ((long)tiles * sk * 4 < 128 && sk < 64 && nk / (2 * sk) >= 4) continue;      // far too few workgroups
+        } else if (sk > 16 || (sk > 1 && (tiles > 200 || nk < 24 || nk / sk < 6 || (long)tiles * sk > 768))) continue;
         float t = 1e30f;
         const int id = tune_cfg(g, st, sk, &t);
         if (id < 0) continue;

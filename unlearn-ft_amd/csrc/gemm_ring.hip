@@ -49,6 +49,144 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform
     }
 }
 
+// Epilogue shared by the ring kernels (same contract as gemm.hip): accumulators -> LDS staging image (64 rows per pass) ->
+// 16-byte rows of C with bias / rowvec / residual / accumulate fused, or fp32 atomics for split-K launches.
+template <int BM, int NJ, int LDS_BYTES>
+__device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&acc)[BM / 64][NJ], unsigned char* smem, int m0,
+                                              int n0) {
+    constexpr int BN = 32 * NJ, IM = BM / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool first = blockIdx.y == 0;
+    const bool atomic = gridDim.y > 1;
+    const bool f32out = g.out_f32 != 0;
+    const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
+    constexpr int SROW = BN + 4;
+    constexpr int C8 = BN / 8;                                        // 8-column chunks per tile row
+    constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
+    float* stage = reinterpret_cast<float*>(smem);
+    static_assert(64 * SROW * 4 <= LDS_BYTES, "staging image must fit the ring");
+    float* Cf = reinterpret_cast<float*>(g.C);
+    bf16* Ct = reinterpret_cast<bf16*>(g.C);
+    const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+#pragma unroll
+    for (int pass = 0; pass < BM / 64; ++pass) {
+        __syncthreads();
+        if ((wm * 16 * IM) / 64 == pass) {
+            const int lrb = (wm * 16 * IM) % 64;
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                    *reinterpret_cast<f32x4*>(stage + (lrb + i * 16 + (lane & 15)) * SROW + wn * (16 * NJ) + j * 16 + (lane >> 4) * 4) = v;
+                }
+        }
+        if (atomic) {
+            __syncthreads();
+            for (int rr = 0; rr < 8; ++rr) {
+                const int lr2 = wave * 8 + rr, m = m0 + pass * 64 + lr2;
+                if (m >= g.M) break;
+#pragma unroll
+                for (int h = 0; h < (BN + 63) / 64; ++h) {
+                    const int cl = h * 64 + lane, n = n0 + cl;
+                    if (cl < BN && n < g.N) {
+                        float v = stage[lr2 * SROW + cl];
+                        if (first) {
+                            if (g.bias) v += g.bias[n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (Rp) v += (float)Rp[(long)m * g.ldr + n];
+                        }
+                        unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
+                    }
+                }
+            }
+        } else if (vec8) {
+            // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
+            bf16x8 rres[ITEMS], cprev[ITEMS];
+            float4 cp0[ITEMS], cp1[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                const bool ok = item < 64 * C8 && m < g.M && n < g.N;
+                const long off = (long)m * g.ldc + n;
+                if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
+                if (ok && g.accumulate) {
+                    if (f32out) { cp0[it] = *reinterpret_cast<const float4*>(Cf + off); cp1[it] = *reinterpret_cast<const float4*>(Cf + off + 4); }
+                    else cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
+                float v[8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8 + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
+                if (g.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (g.rowvec) {
+                    const float* rv = g.rowvec + (long)(m / g.rows_per_b) * g.N + n;
+                    const float4 b0 = *reinterpret_cast<const float4*>(rv), b1 = *reinterpret_cast<const float4*>(rv + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (Rp) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)rres[it][r];
+                }
+                const long off = (long)m * g.ldc + n;
+                if (f32out) {
+                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+                    if (g.accumulate) {
+                        o0.x += cp0[it].x; o0.y += cp0[it].y; o0.z += cp0[it].z; o0.w += cp0[it].w;
+                        o1.x += cp1[it].x; o1.y += cp1[it].y; o1.z += cp1[it].z; o1.w += cp1[it].w;
+                    }
+                    *reinterpret_cast<float4*>(Cf + off) = o0;
+                    *reinterpret_cast<float4*>(Cf + off + 4) = o1;
+                } else {
+                    if (g.accumulate) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += (float)cprev[it][r];
+                    }
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
+                    *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                }
+            }
+        } else {
+            __syncthreads();
+            for (int item = tid; item < 64 * C8; item += NT) {
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                if (m >= g.M || n >= g.N) continue;
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+                const long off = (long)m * g.ldc + n;
+                const int nv = min(8, g.N - n);
+                for (int r = 0; r < nv; ++r) {
+                    float x = stage[lr2 * SROW + c8 * 8 + r];
+                    if (g.bias) x += g.bias[n + r];
+                    if (rv) x += rv[n + r];
+                    if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
+                    if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
+                    else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
+                }
+            }
+        }
+    }
+}
+
 template <bool CONV, int BM, int NJ, int STAGES, int OCC>
 __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
     typedef Mma<bf16> MM;
@@ -181,135 +319,153 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
-    // ---------------------------------------------------------------- epilogue (same contract as gemm.hip)
-    const bool first = blockIdx.y == 0;
-    const bool atomic = gridDim.y > 1;
-    const bool f32out = g.out_f32 != 0;
-    const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
-    constexpr int SROW = BN + 4;
-    constexpr int C8 = BN / 8;                                        // 8-column chunks per tile row
-    constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
-    float* stage = reinterpret_cast<float*>(smem);
-    static_assert(64 * SROW * 4 <= STAGES * SLOT, "staging image must fit the ring");
-    float* Cf = reinterpret_cast<float*>(g.C);
-    bf16* Ct = reinterpret_cast<bf16*>(g.C);
-    const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+    ring_epilogue<BM, NJ, STAGES * SLOT>(g, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM: C[m][n] += sum_k A(k,m) B(k,n) with BOTH operands reduction-major (k = pixel rows):
+// A = dY [P][M], B = X [P][N] (Linear) or the 3x3 gather of X (conv: column n = tap*Ci + c reads pixel src(p, tap)).
+// Same ring as above with [64 k][128 col] tiles (256-byte rows, a DMA piece = 4 k-rows); the MFMA operands are read
+// with ds_read_b64_tr_b16.  Swizzle: 16-byte chunk index ^= 2*f(k), f(k) = (k&3) | ((k>>3)&1)<<2, applied to the source
+// column of each DMA lane and to the transposing reads: the 8 k-rows one 32-lane read group touches land in 8 different
+// 32-byte bank groups.  The bias gradient (column sums of dY) is one extra MFMA per A fragment against a ones vector, in
+// the workgroups of the first n-tile only.
+template <bool CONV, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
+                                                             unsigned b_bytes) {
+    typedef Mma<bf16> MM;
+    constexpr int BM = 128, NJ = 4, BN = 128, IM = 2;
+    constexpr int T_BYTES = 64 * 256, SLOT = 2 * T_BYTES;       // A tile + B tile, 16 KiB each
+    static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int nk_total = (g.K + BK - 1) / BK;
+    const int per = (nk_total + gridDim.y - 1) / gridDim.y;
+    const int kt0 = blockIdx.y * per;
+    const int kt1 = min(nk_total, kt0 + per);
+    if (kt0 >= kt1) return;
+
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
+    const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld, g.conv_mode};
+
+    // ---- loader: piece (i*8 + wave) of a tile = k-rows 4*(i*8+wave) .. +3; lane -> (row lane>>4, physical chunk lane&15)
+    const int kr_l = lane >> 4;                                      // k-row inside the piece
+    const int fsw = kr_l | (((wave >> 1) & 1) << 2);                 // f(k) of every row this lane loads
+    const int lcn = (lane & 15) ^ (fsw << 1);                        // logical 16-byte chunk = 8 columns
+    const int acol = m0 + lcn * 8, bcol = n0 + lcn * 8;
+    const bool a_ok = acol < g.M, b_ok = bcol < g.N;
+    int b_tap = 0, b_ci = 0;
+    if (CONV) {
+        b_tap = bcol / cg.ci;
+        b_ci = bcol - b_tap * cg.ci;
+    }
+
+    auto issue = [&](int kt, int slot) {
+        unsigned char* sa = smem + slot * SLOT;
 #pragma unroll
-    for (int pass = 0; pass < BM / 64; ++pass) {
-        __syncthreads();
-        if ((wm * 16 * IM) / 64 == pass) {
-            const int lrb = (wm * 16 * IM) % 64;
+        for (int i = 0; i < 2; ++i) {
+            const int piece = i * 8 + wave;
+            const int kr = kt * BK + piece * 4 + kr_l;               // pixel row
+            const bool kok = kr < g.K;
+            const unsigned va = (kok && a_ok) ? ((unsigned)kr * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + piece * 1024), 16, (int)va, 0, 0, 0);
+            unsigned vb = OOB;
+            if (CONV) {
+                if (kok && b_ok) {
+                    int b, oy, ox;
+                    if (lg_wo >= 0) {                                // power-of-two image: shifts instead of divisions
+                        b = kr >> lg_howo;
+                        const int rem = kr & ((1 << lg_howo) - 1);
+                        oy = rem >> lg_wo;
+                        ox = rem & ((1 << lg_wo) - 1);
+                    } else {
+                        const int hw = cg.ho * cg.wo;
+                        b = kr / hw;
+                        const int rem = kr - b * hw;
+                        oy = rem / cg.wo;
+                        ox = rem - oy * cg.wo;
+                    }
+                    const int px = conv_src_pixel(cg, b, oy, ox, b_tap);
+                    if (px >= 0) vb = ((unsigned)px * (unsigned)cg.ld + (unsigned)b_ci) * 2u;
+                }
+            } else if (kok && b_ok) {
+                vb = ((unsigned)kr * (unsigned)g.ldb + (unsigned)bcol) * 2u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + T_BYTES + piece * 1024), 16, (int)vb, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[IM][NJ], acs[IM];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+        acs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_colsum = g.colsum_out != nullptr && n0 == 0 && wn == 0;      // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    // transposing fragment reads: lane (g = lane>>4, q = (lane&15)>>2, p = lane&3) reads 8 bytes of k-row kk + 8g + q (and of
+    // row + 4) at columns col0 + 4p; physical chunk = ((col0>>3) ^ 2 f) | (p>>1), f = q | (g&1)<<2
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned t_row = (unsigned)(8 * tg + tq) * 256u + (unsigned)(tp & 1) * 8u;
+    const int t_f2 = (tq | ((tg & 1) << 2)) << 1;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto tr_frag = [&](const unsigned char* base, int kk, int col0) -> bf16x8 {
+        const unsigned ch = (unsigned)(((col0 >> 3) ^ t_f2) | (tp >> 1));
+        const unsigned char* a0 = base + (unsigned)kk * 256u + t_row + ch * 16u;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 256));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (kt0 + s < kt1) issue(kt0 + s, s);
+
+    int slot = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int ahead = min(STAGES - 2, kt1 - 1 - kt);
+        wait_vmcnt_dyn(ahead * 4);
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, slot == 0 ? STAGES - 1 : slot - 1);
+        const unsigned char* sa = smem + slot * SLOT;
+        const unsigned char* sb = sa + T_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 32) {
+            bf16x8 af[IM], bf[NJ];
+#pragma unroll
+            for (int i = 0; i < IM; ++i) af[i] = tr_frag(sa, kk, wm * 32 + i * 16);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = tr_frag(sb, kk, wn * 64 + j * 16);
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x4 v = acc[i][j];
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            if (do_colsum) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
-                    *reinterpret_cast<f32x4*>(stage + (lrb + i * 16 + (lane & 15)) * SROW + wn * (16 * NJ) + j * 16 + (lane >> 4) * 4) = v;
-                }
+                for (int i = 0; i < IM; ++i) acs[i] = MM::mma(ones, af[i], acs[i]);
+            }
         }
-        if (atomic) {
-            __syncthreads();
-            for (int rr = 0; rr < 8; ++rr) {
-                const int lr2 = wave * 8 + rr, m = m0 + pass * 64 + lr2;
-                if (m >= g.M) break;
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    if (do_colsum && (lane >> 4) == 0) {
 #pragma unroll
-                for (int h = 0; h < (BN + 63) / 64; ++h) {
-                    const int cl = h * 64 + lane, n = n0 + cl;
-                    if (cl < BN && n < g.N) {
-                        float v = stage[lr2 * SROW + cl];
-                        if (first) {
-                            if (g.bias) v += g.bias[n];
-                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
-                            if (Rp) v += (float)Rp[(long)m * g.ldr + n];
-                        }
-                        unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
-                    }
-                }
-            }
-        } else if (vec8) {
-            // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
-            bf16x8 rres[ITEMS], cprev[ITEMS];
-            float4 cp0[ITEMS], cp1[ITEMS];
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
-                const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
-                const bool ok = item < 64 * C8 && m < g.M && n < g.N;
-                const long off = (long)m * g.ldc + n;
-                if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
-                if (ok && g.accumulate) {
-                    if (f32out) { cp0[it] = *reinterpret_cast<const float4*>(Cf + off); cp1[it] = *reinterpret_cast<const float4*>(Cf + off + 4); }
-                    else cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
-                const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
-                if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
-                float v[8];
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8 + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = lo[r]; v[4 + r] = hi[r]; }
-                if (g.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(g.bias + n), b1 = *reinterpret_cast<const float4*>(g.bias + n + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
-                if (g.rowvec) {
-                    const float* rv = g.rowvec + (long)(m / g.rows_per_b) * g.N + n;
-                    const float4 b0 = *reinterpret_cast<const float4*>(rv), b1 = *reinterpret_cast<const float4*>(rv + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
-                if (Rp) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += (float)rres[it][r];
-                }
-                const long off = (long)m * g.ldc + n;
-                if (f32out) {
-                    float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.accumulate) {
-                        o0.x += cp0[it].x; o0.y += cp0[it].y; o0.z += cp0[it].z; o0.w += cp0[it].w;
-                        o1.x += cp1[it].x; o1.y += cp1[it].y; o1.z += cp1[it].z; o1.w += cp1[it].w;
-                    }
-                    *reinterpret_cast<float4*>(Cf + off) = o0;
-                    *reinterpret_cast<float4*>(Cf + off + 4) = o1;
-                } else {
-                    if (g.accumulate) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] += (float)cprev[it][r];
-                    }
-                    bf16x8 o;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-                    *reinterpret_cast<bf16x8*>(Ct + off) = o;
-                }
-            }
-        } else {
-            __syncthreads();
-            for (int item = tid; item < 64 * C8; item += NT) {
-                const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
-                if (m >= g.M || n >= g.N) continue;
-                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
-                const long off = (long)m * g.ldc + n;
-                const int nv = min(8, g.N - n);
-                for (int r = 0; r < nv; ++r) {
-                    float x = stage[lr2 * SROW + c8 * 8 + r];
-                    if (g.bias) x += g.bias[n + r];
-                    if (rv) x += rv[n + r];
-                    if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
-                    if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
-                    else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
-                }
-            }
+        for (int i = 0; i < IM; ++i) {
+            const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+            if (m < g.M) unsafeAtomicAdd(g.colsum_out + m, acs[i][0]);
         }
     }
+    ring_epilogue<BM, NJ, STAGES * SLOT>(g, acc, smem, m0, n0);
 }
 
 struct Config {
@@ -372,5 +528,31 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
         default: return 1;
     }
 #undef PDMK_RING_GO
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// ---- weight-gradient ring: id 0 = 4-slot ring (one workgroup per CU), id 1 = 2-slot ring (two per CU)
+int pdmk_wgrad_ring_num_configs() { return 2; }
+int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
+    using namespace pdmk_ring;
+    if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
+    const bool conv = g.b_mode == PDMK_B_COLK_CONV;
+    if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
+    if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode > 2)) return 1;
+    int lg_wo = -1, lg_howo = -1;
+    if (conv) {
+        auto lg = [](int v) { int l = 0; if (v <= 0 || (v & (v - 1))) return -1; while ((1 << l) < v) ++l; return l; };
+        lg_wo = lg(g.conv_wo);
+        lg_howo = lg(g.conv_ho * g.conv_wo);
+        if (lg_wo < 0 || lg_howo < 0) lg_wo = lg_howo = -1;
+    }
+    dim3 grid(((g.M + 127) / 128) * ((g.N + 127) / 128), g.splitk > 1 ? g.splitk : 1);
+#define PDMK_WG_GO(CV, STv, OCv)                                                                                      \
+    hipLaunchKernelGGL((wgrad_ring_kernel<CV, STv, OCv>), grid, dim3(NT), 0, st, g, lg_wo, lg_howo, (unsigned)a_bytes, \
+                       (unsigned)b_bytes)
+    if (id == 0) { if (conv) PDMK_WG_GO(true, 4, 2); else PDMK_WG_GO(false, 4, 2); }
+    else if (id == 1) { if (conv) PDMK_WG_GO(true, 2, 4); else PDMK_WG_GO(false, 2, 4); }
+    else return 1;
+#undef PDMK_WG_GO
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

@@ -153,6 +153,22 @@ def splitk_plan(A, B, M, N, K, lda, ldb, a_mode=A_ROWK, conv=None):
     return int(sk.value)
 
 
+def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None):
+    """Split-K factor for a weight-gradient GEMM dW[M,N] += dy[K,M]^T x[K,N] (both operands reduction-major)."""
+    g = GemmArgs()
+    g.A, g.B = _p(dy), _p(x)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = lda, ldb, N
+    g.a_mode, g.b_mode = A_COLK, b_mode
+    if conv is not None:
+        (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
+    g.dtype = dt(x)
+    g.out_f32, g.splitk, g.alpha = 1, 1, 1.0
+    sk = i32(1)
+    _chk(_lib.pdmk_gemm_plan(C.byref(g), _st(), C.byref(sk)), "pdmk_gemm_plan")
+    return int(sk.value)
+
+
 def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
               a_mode=A_ROWK, conv=None, accumulate=False, macs=None):
     """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace."""

@@ -132,8 +132,8 @@ class UNetEngine:
                     dyc = self._empty(M, Np)
                     k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
                     dy = dyc
-                sk = self._splitk(Np, Kp, M, 64)
                 xt = x.t
+                sk = k.wgrad_plan(dy, xt, Np, Kp, M, _ld(dy), _ld(xt))
                 # wgrad first (side stream), dgrad second (main stream): the two GEMMs of one layer run side by side
                 self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), Kp,
                                            a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
@@ -172,8 +172,8 @@ class UNetEngine:
             def bwd():
                 dy = out.g
                 ldy = _ld(dy)
-                sk = self._splitk(Cop, 9 * Cip, M, 64)
                 xt = x.t
+                sk = k.wgrad_plan(dy, xt, Cop, 9 * Cip, M, ldy, 0, k.B_COLK_CONV, (B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)))
                 self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip,
                                            a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
                                            conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), out_f32=True, splitk=sk,
