@@ -195,42 +195,51 @@ def main():
         extras["model_tflops_per_gpu"] = round((a.steps * flop_main + n_upper * flop_upper) / el / 1e12, 2)
     roof = None
     if rank == 0 and not a.no_roofline and world == 1:
+        # Dominant kernel: one eager main step with every GEMM launch bracketed by HIP events on its launch stream
+        # (pdm._pdmk.PROFILE) and labelled with the candidate kernel the library's plan cache picked; the teacher runs
+        # in line here (no second stream) so that an event pair times one kernel, not two overlapped ones.
+        ts, st.teacher_stream = st.teacher_stream, None
         k.PROFILE = []
         main_iter(0)
         torch.cuda.synchronize()
         prof, k.PROFILE = k.PROFILE, None
-        agg = {}
+        st.teacher_stream = ts
         if os.environ.get("PDMK_DUMP_GEMM"):
             with open(os.environ["PDMK_DUMP_GEMM"], "w") as f:
                 for kind, flops, e0, e1, shp in prof:
                     f.write(json.dumps({"kind": list(kind), "flops": flops, "ms": e0.elapsed_time(e1), "mnk_sk": shp}) + "\n")
+        agg, cls = {}, {}
         for kind, flops, e0, e1, shp in prof:
             ms = e0.elapsed_time(e1)
-            r = agg.setdefault(kind, [0.0, 0.0, 0])
-            r[0] += flops
-            r[1] += ms
-            r[2] += 1
+            for d, key in ((agg, kind), (cls, kind[:3])):
+                r = d.setdefault(key, [0.0, 0.0, 0])
+                r[0] += flops
+                r[1] += ms
+                r[2] += 1
+        class_names = {(0, 0): "linear fwd/dgrad", (1, 0): "conv3x3 fwd/dgrad (implicit GEMM)",
+                       (2, 1): "linear wgrad", (2, 2): "conv3x3 wgrad"}
+        sym = lambda kd: k.candidate_name(kd[1], kd[2], kd[3])
         dom = max(agg.items(), key=lambda kv: kv[1][1])
-        names = {(0, 0): "igemm<rowk,rowk> (linear fwd/dgrad)", (1, 0): "igemm<conv,rowk> (conv3x3 fwd/dgrad)",
-                 (2, 1): "igemm<colk,colk> (linear wgrad)", (2, 2): "igemm<colk,colk_conv> (conv3x3 wgrad)"}
         ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
         peak = 2500.0 if a.dtype == "bf16" else 157.3
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_igemm.json")
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
         if os.path.exists(tfile) and not a.tiny:
-            # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # same command (tools/summarize_pmc.py; gfx950 2x FETCH_SIZE correction applied); counters cannot be read live
-            short = {(0, 0): "rowk,rowk", (1, 0): "conv,rowk", (2, 1): "colk,colk", (2, 2): "colk,colk_conv"}
-            rec = json.load(open(tfile)).get(f"{dom[0][0]} igemm<{short[(dom[0][1], dom[0][2])]}>")
+            # HBM bytes per launch of this kernel symbol from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+            # this same command (tools/summarize_pmc.py; gfx950 2x FETCH_SIZE correction applied); counters cannot be read live
+            rec = json.load(open(tfile)).get(sym(dom[0]))
             traffic = rec and round(rec["hbm_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": f"{dom[0][0]} {names[(dom[0][1], dom[0][2])]}",
+        top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]
+        roof = {"bound": "mfma", "kernel": sym(dom[0]), "kernel_class": class_names[dom[0][1:3]],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic_igemm.json)",
+                "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)",
                 "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
                 "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),
-                "all_gemm_kinds": {f"{kd[0]} {names[(kd[1], kd[2])]}": {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
-                                                                         "ms": round(v[1], 2), "launches": v[2]}
-                                   for kd, v in agg.items()}}
+                "gemm_classes": {class_names[kd[1:3]]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 2),
+                                                        "launches": v[2]} for kd, v in cls.items()},
+                "top_kernels": {sym(kd) + " | " + class_names[kd[1:3]]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2),
+                                                                        "ms": round(v[1], 2), "launches": v[2]}
+                                for kd, v in top}}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         del data

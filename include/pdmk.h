@@ -83,6 +83,11 @@ int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
  * (tile shapes x split factors) on the device, blocking the host for a few ms, and caches the winner for the process;
  * inside a capture, or with PDMK_GEMM_TUNE=0, a static heuristic answers instead. */
 int pdmk_gemm_plan(const pdmk_gemm_args* args, pdmk_stream stream, int32_t* splitk_out);
+/* Measurement helpers: the candidate kernel the calling thread's last pdmk_gemm launched (0 = K-step-32 kernels,
+ * 1.. = LDS-DMA ring shapes) and the symbol name a profiler reports for (a_mode, b_mode, candidate).
+ * PDMK_PLAN_CACHE=<file> persists the plan cache across processes; PDMK_GEMM_TUNE=0 disables on-device tuning. */
+int pdmk_gemm_last_candidate(void);
+int pdmk_gemm_candidate_name(int a_mode, int b_mode, int id, char* buf, int n);
 /* Second half of a split-K forward/dgrad GEMM (small-M layers at 8x8 / 16x16 latents: too few output tiles to fill 256
  * CUs): pdmk_gemm accumulated fp32 partials into the zeroed workspace ws[M,N] (out_f32, splitk>1); this applies the
  * epilogue C = (accumulate ? C : 0) + ws + bias + rowvec + R and stores in `dtype`. */

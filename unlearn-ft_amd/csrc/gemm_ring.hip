@@ -11,6 +11,7 @@
 //     chunk index with (row>>1)&7 on the SOURCE address and on the fragment reads (same involution on both sides).
 #include "common.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace pdmk_ring {
@@ -501,6 +502,18 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
 }  // namespace pdmk_ring
 
 int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs; }
+int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demangled symbol rocprofv3 reports
+    using namespace pdmk_ring;
+    if (id < 0 || id >= kNumConfigs) return -1;
+    const Config c = kConfigs[id];
+    snprintf(buf, n, "pdmk_ring::igemm_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
+    return 0;
+}
+int pdmk_wgrad_ring_name(int id, int conv, char* buf, int n) {
+    if (id < 0 || id > 1) return -1;
+    snprintf(buf, n, "pdmk_ring::wgrad_ring_kernel<%s, %d, %d>", conv ? "true" : "false", id == 0 ? 4 : 2, id == 0 ? 2 : 4);
+    return 0;
+}
 int pdmk_gemm_ring_pick(const pdmk_gemm_args& g) { return pdmk_ring::pick_config(g, g.splitk); }
 
 // called by pdmk_gemm (gemm.hip) after argument validation; returns 1 if the shape/config is not handled here

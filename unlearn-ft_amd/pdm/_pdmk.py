@@ -46,6 +46,8 @@ _SIGS = {
     "pdmk_version": ([], i32),
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
+    "pdmk_gemm_last_candidate": ([], i32),
+    "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -133,8 +135,14 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     e0.record()
     _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
     e1.record()
-    kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode)
+    kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode, _lib.pdmk_gemm_last_candidate())
     PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
+
+
+def candidate_name(a_mode, b_mode, cand):
+    buf = C.create_string_buffer(160)
+    _chk(_lib.pdmk_gemm_candidate_name(a_mode, b_mode, cand, buf, 160), "pdmk_gemm_candidate_name")
+    return buf.value.decode()
 
 
 def splitk_plan(A, B, M, N, K, lda, ldb, a_mode=A_ROWK, conv=None):

@@ -324,7 +324,13 @@ class GraphedBilevel:
         store = st.student.store
         opts = [o for o in (st.opt, st.upper_opt) if o is not None]
         snap = [store.master.clone(), store.grad.clone()] + [t_.clone() for o in opts for t_ in (o.m, o.v)]
-        # eager warm-up on a side stream (allocator + lazy tables), as torch.cuda.graphs requires
+        # eager warm-up on a side stream (allocator + lazy tables), as torch.cuda.graphs requires.  It is also where the
+        # library times its GEMM candidates for every shape of the step (plan cache), so the static inputs hold random
+        # data for it: all-zero operands run at a higher clock and would rank the candidates differently.
+        gen = torch.Generator(device=self.lat.device).manual_seed(1234)
+        for buf in (self.lat, self.noise, self.ehs, self.empty):
+            buf.normal_(generator=gen)
+        self.t.random_(0, 1000, generator=gen)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
