@@ -36,7 +36,6 @@ def parse():
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--no_graph", action="store_true", help="eager Python launches instead of hipGraph replay")
-    p.add_argument("--force_graph", action="store_true", help="hipGraph replay also for N > 1 (all-reduce not overlapped)")
     return p.parse_args()
 
 
@@ -127,13 +126,11 @@ def main():
         st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], empty)
         st.optimizer_step(upper=True)
 
-    # 1 GPU: hipGraph replay (immune to host jitter).  N > 1: eager multi-stream launches, because there the bucketed
-    # RCCL all-reduce is issued from the backward tape and overlaps with the rest of the backward pass (in graph mode
-    # it would run exposed between the two graphs); eager mode also moves the weight-gradient GEMMs to a side stream,
-    # which keeps the queues full while Python launches (measured: eager 55.3 vs graph 55.0 ms per main step on one
-    # GPU; inside a graph the side stream costs 2%, so it stays off there).  --force_graph / --no_graph override.
-    use_graph = (world == 1 and not a.no_graph) or a.force_graph
-    student.engine.wgrad_async = not use_graph
+    # hipGraph replay (immune to host jitter) on every rank count.  With N > 1 the backward is captured as 6 graphs cut at
+    # block boundaries of the tape, and the bucketed RCCL all-reduce of each finished sixth of the gradient arena is
+    # issued on the comm stream between the replays, i.e. it overlaps with the rest of the backward pass.
+    # --no_graph: eager launches (all-reduce buckets issued from the backward tape).
+    use_graph = not a.no_graph
     graphs = None
     if use_graph:
         graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)

@@ -181,6 +181,10 @@ int pdmk_mse_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const f
 int pdmk_mse_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, void* da, int B,
                  int64_t rows_per_b, int cols, int lda, int ldb, int ldda, float gscale, int accumulate,
                  pdmk_stream stream);
+/* Zero nbytes (multiple of 16, 16-byte aligned) with a kernel.  Used instead of hipMemsetAsync for split-K workspaces
+ * and gradient seeds: memset nodes captured into the 2nd..nth hipGraph of a shared memory pool (the segmented backward
+ * graphs of the multi-GPU path) were seen to leave the buffer unzeroed on replay (ROCm 7.2). */
+int pdmk_zero(void* p, int64_t nbytes, pdmk_stream stream);
 /* y = alpha*x + beta*y over n contiguous elements (dtype). */
 int pdmk_axpby(const void* x, void* y, float alpha, float beta, int64_t n, int dtype, pdmk_stream stream);
 

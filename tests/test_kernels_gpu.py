@@ -413,7 +413,7 @@ def force_cfg():
         os.environ.pop(var, None)
 
 
-@pytest.mark.parametrize("cand", list(range(12)))
+@pytest.mark.parametrize("cand", list(range(13)))
 def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
     """Every fwd/dgrad candidate of the plan cache gives the same linear + 3x3-conv results (ragged M/N/K tails, K not
     a multiple of the K-step, stride-2 / upsample / transposed gathers, split-K with fp32 atomics)."""
@@ -484,3 +484,27 @@ def test_ring_wgrad_candidates(dev, force_cfg, cand):
                conv=(Bn, Hs, Hs, Ci, Ho, Ho, mode, Ci), colsum_out=db)
         close(dW, conv_w_pack(gw), 2e-2, f"wgrad conv mode {mode}")
         close(db, dy.float().sum(dim=(0, 1, 2)), 2e-2, "fused conv bias gradient")
+
+
+@pytest.mark.parametrize("cand", [13, 14, 15, 16])
+def test_halo_conv_candidates(dev, force_cfg, cand):
+    """conv_halo_kernel (input patch staged once per 64-channel block, 9 taps out of LDS) vs F.conv2d: row-group tiles,
+    whole-image tiles, several images per tile with a missing last image, channel tails, split-K over channel blocks."""
+    from pdm import _pdmk as k
+    force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(9)
+    dt = torch.bfloat16
+    for Bn, Hs, Ci, Co, sk in ((2, 16, 96, 72, 1), (3, 8, 64, 160, 1), (1, 32, 160, 64, 1), (2, 64, 32, 320, 1), (2, 16, 160, 136, 2)):
+        x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+        w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
+        bias = torch.randn(Co, device=dev)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias if sk == 1 else None, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+        M = Bn * Hs * Hs
+        if sk == 1:
+            y = torch.zeros(M, Co, device=dev, dtype=dt)
+            k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci), bias=bias)
+        else:
+            y = torch.zeros(M, Co, device=dev)
+            k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci),
+                   out_f32=True, splitk=sk)
+        close(y, ref, 2e-2, f"halo conv B{Bn} {Hs}x{Hs} {Ci}->{Co} sk{sk}")

@@ -239,11 +239,20 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, flo
         for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[(long)blockIdx.z * N + c * V + e], s[e]);
     }
 }
+__global__ void zero_f32_kernel(float* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
 template <typename T>
 int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nbatch, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (N % V || ld % V) return -1;
-    if (!acc && hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * nbatch, st) != hipSuccess) return -1000;
+    // a kernel, not hipMemsetAsync: memset nodes captured into the 2nd..nth hipGraph of a shared memory pool were seen to
+    // leave the buffer unzeroed on replay (segmented backward graphs, ROCm 7.2)
+    if (!acc) {
+        const long n = (long)N * nbatch;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n);
+    }
     const int nc = N / V;
     int tpr = 1;
     while (tpr < nc && tpr < NT) tpr <<= 1;
@@ -526,6 +535,19 @@ extern "C" int pdmk_transpose_tiles(const void* src, void* dst, const int32_t* t
     PDMK_CHECK_LAUNCH();
     return 0;
 }
+__global__ void zero_bytes_kernel(uint4* __restrict__ p, long n16) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+extern "C" int pdmk_zero(void* p, int64_t nbytes, pdmk_stream s) {
+    if (!p || nbytes < 0 || (nbytes & 15) || ((uintptr_t)p & 15)) return -1;
+    if (nbytes == 0) return 0;
+    const long n16 = nbytes / 16;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)s, (uint4*)p, n16);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch,
                            int dtype, pdmk_stream s) {
     if (!x || !out || rows <= 0 || N <= 0 || nbatch <= 0) return -1;

@@ -522,6 +522,11 @@ void plan_file_load() {
     if (!path) return;
     FILE* f = fopen(path, "r");
     if (!f) return;
+    int ver = 0;
+    if (fscanf(f, " pdmk-plan %d", &ver) != 1 || ver != pdmk_version()) {     // candidate numbering of another build
+        fclose(f);
+        return;
+    }
     char kind;
     PlanKey k;
     int val;
@@ -535,8 +540,13 @@ void plan_file_load() {
 void plan_file_append(char kind, const PlanKey& k, int val) {
     const char* path = getenv("PDMK_PLAN_CACHE");
     if (!path) return;
-    FILE* f = fopen(path, "a");
+    FILE* probe = fopen(path, "r");
+    int ver = 0;
+    const bool fresh = !probe || fscanf(probe, " pdmk-plan %d", &ver) != 1 || ver != pdmk_version();
+    if (probe) fclose(probe);
+    FILE* f = fopen(path, fresh ? "w" : "a");
     if (!f) return;
+    if (fresh) fprintf(f, "pdmk-plan %d\n", pdmk_version());
     fprintf(f, "%c %d %d %d %d %d %d %d %d %d %d %d\n", kind, k.v[0], k.v[1], k.v[2], k.v[3], k.v[4], k.v[5], k.v[6], k.v[7],
             k.v[8], k.v[9], val);
     fclose(f);
@@ -807,4 +817,4 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 102; }
+extern "C" int pdmk_version(void) { return 104; }

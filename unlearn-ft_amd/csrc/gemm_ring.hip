@@ -107,7 +107,6 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
         } else if (vec8) {
             // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
             bf16x8 rres[ITEMS], cprev[ITEMS];
-            float4 cp0[ITEMS], cp1[ITEMS];
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = tid + it * NT;
@@ -116,10 +115,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                 const bool ok = item < 64 * C8 && m < g.M && n < g.N;
                 const long off = (long)m * g.ldc + n;
                 if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
-                if (ok && g.accumulate) {
-                    if (f32out) { cp0[it] = *reinterpret_cast<const float4*>(Cf + off); cp1[it] = *reinterpret_cast<const float4*>(Cf + off + 4); }
-                    else cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
-                }
+                if (ok && g.accumulate && !f32out) cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
             }
             __syncthreads();
 #pragma unroll
@@ -149,9 +145,10 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                 const long off = (long)m * g.ldc + n;
                 if (f32out) {
                     float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.accumulate) {
-                        o0.x += cp0[it].x; o0.y += cp0[it].y; o0.z += cp0[it].z; o0.w += cp0[it].w;
-                        o1.x += cp1[it].x; o1.y += cp1[it].y; o1.z += cp1[it].z; o1.w += cp1[it].w;
+                    if (g.accumulate) {       // fp32 accumulate (weight gradients without split-K): read in place
+                        const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
+                        o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
+                        o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
                     }
                     *reinterpret_cast<float4*>(Cf + off) = o0;
                     *reinterpret_cast<float4*>(Cf + off + 4) = o1;
@@ -324,6 +321,171 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Stride-1 3x3 convolution with the input halo staged ONCE per channel block ("halo conv"): an output tile is R image
+// rows (or whole small images); for every 64-channel block its (R+2) x (W+2) input patch is DMA-ed into LDS once and
+// the 9 taps run out of it as shifted fragment reads, instead of gathering the A tile 9 times from L2.  K order is
+// (channel block, tap); weight tiles [BN][64] stream through a BSTAGES ring, the patch is double-buffered (the next
+// block's pieces are issued one per tap).  Per 64 channels a 256x160 tile takes in 50 + 9x20 KiB instead of 9 x 52 KiB:
+// half the operand intake per FLOP and a ninth of the activation traffic.  Patch swizzle: chunk ^= (patch row & 7),
+// conflict-free for every tap shift; weight tiles keep the (row>>1)&7 swizzle of the ring kernel.
+// Every loop event issues the same number of DMA instructions per wave (weight tile + one patch piece; surplus pieces
+// re-issue piece 0 = identical bytes, or read out of bounds = zeros into the finished buffer), so the counted
+// s_waitcnt is a constant.
+template <int BM, int NJ, int BSTAGES, int PMAX>
+__global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    typedef Mma<bf16> MM;
+    constexpr int BN = 32 * NJ, IM = BM / 64;
+    constexpr int P_BYTES = PMAX * 128, B_BYTES = BN * 128;
+    constexpr int NBLK_B = BN / 8, NB = (NBLK_B + 7) / 8;
+    constexpr int NPW = (PMAX / 8 + 7) / 8;                          // patch pieces per wave (max)
+    static_assert(PMAX % 8 == 0 && NPW <= 9 - (BSTAGES - 1), "whole pieces; next block's patch issued before its first weight tile");
+    static_assert(2 * P_BYTES + BSTAGES * B_BYTES <= 160 * 1024, "LDS");
+    static_assert(64 * (BN + 4) * 4 <= 2 * P_BYTES, "epilogue staging fits the patch buffers");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * P_BYTES + BSTAGES * B_BYTES];
+    unsigned char* const bring = smem + 2 * P_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (g.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int H = g.conv_hi, W = g.conv_wi, Ci = g.conv_ci, HW = H * W;
+    const int ncb_total = (Ci + 63) / 64;
+    const int per = (ncb_total + gridDim.y - 1) / gridDim.y;
+    const int cb0 = blockIdx.y * per, cb1 = min(ncb_total, cb0 + per);
+    if (cb0 >= cb1) return;
+
+    // tile geometry: R rows of one image (HW >= BM) or BM/HW whole images
+    const int rimg = HW >= BM ? BM / W : H;                           // rows of an image inside the tile
+    const int W2 = W + 2, pimg = (rimg + 2) * W2;                     // patch rows per image
+    const int nimg = HW >= BM ? 1 : BM / HW;
+    const int prows = nimg * pimg;
+    const int img0 = m0 / HW, y0 = (m0 - img0 * HW) / W;              // first image / first output row of the tile
+
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
+
+    // ---- patch loader: piece j of this wave = patch rows 8*(j*8+wave) .. +7; lane -> (row sr = lane>>3, physical chunk lane&7)
+    const int sr = lane >> 3;
+    const int lcp = (lane & 7) ^ sr;                                  // logical chunk (8 channels) of this lane, patch
+    unsigned poff[NPW];                                               // byte offset of the source pixel, or OOB
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int prow = (j * 8 + wave) * 8 + sr;
+        poff[j] = OOB;
+        if (prow < prows) {
+            const int il = prow / pimg, rem = prow - il * pimg;
+            const int py = rem / W2, px = rem - py * W2;
+            const int b = img0 + il, y = y0 + py - 1, x = px - 1;
+            if (b < g.conv_b && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                poff[j] = (unsigned)((b * H + y) * W + x) * (unsigned)g.conv_ld * 2u;
+        }
+    }
+    // ---- weight loader (as in the ring kernel)
+    const int lcb = (lane & 7) ^ (((wave & 1) * 4) + (sr >> 1));
+    unsigned b_base[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int n = n0 + (i * 8 + wave) * 8 + sr;
+        b_base[i] = (n < g.N) ? (unsigned)n * (unsigned)g.ldb * 2u : OOB;
+    }
+    const int nb_wave = NBLK_B / 8 + (wave < (NBLK_B % 8) ? 1 : 0);
+
+    auto issue_piece = [&](int cb, unsigned off, int jj) {            // piece jj of patch(cb) from source offset `off`
+        const int ch = cb * 64 + lcp * 8;
+        const unsigned va = (off != OOB && ch < Ci && cb < cb1) ? off + (unsigned)ch * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(smem + (cb & 1) * P_BYTES + (jj * 8 + wave) * 1024), 16,
+                                                 (int)va, 0, 0, 0);
+    };
+    auto issue_b = [&](int cb, int tap, int slot) {
+        unsigned char* sb = bring + slot * B_BYTES;
+        const int ch = cb * 64 + lcb * 8;
+        const unsigned koff = (unsigned)(tap * Ci + ch) * 2u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i * 8 + wave < NBLK_B) {
+                const unsigned vb = (b_base[i] != OOB && ch < Ci) ? b_base[i] + koff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sb + (i * 8 + wave) * 1024), 16, (int)vb, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[IM][NJ];
+#pragma unroll
+    for (int i = 0; i < IM; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing.  A: patch row of output pixel (wm*16*IM + i*16 + fr) for tap (0,0); B: as the ring kernel
+    const int fr = lane & 15, fg = lane >> 4;
+    int prow0[IM];
+#pragma unroll
+    for (int i = 0; i < IM; ++i) {
+        const int ml = wm * (16 * IM) + i * 16 + fr;                  // output pixel inside the tile
+        const int il = ml / (rimg * W), rem = ml - il * (rimg * W);
+        const int yl = rem / W, x = rem - yl * W;
+        prow0[i] = il * pimg + yl * W2 + x;
+    }
+    const int fsw = (fr >> 1) & 7;
+    const unsigned fch0 = (unsigned)((fg ^ fsw) * 16), fch1 = (unsigned)(((4 + fg) ^ fsw) * 16);
+    const unsigned b_row = (unsigned)(wn * (16 * NJ) + fr) * 128u;
+
+    // ---- prologue: the first patch, then BSTAGES-1 weight tiles
+    const int nsteps = (cb1 - cb0) * 9;
+#pragma unroll
+    for (int j = 0; j < NPW; ++j)
+        if ((j * 8 + wave) * 8 < prows) issue_piece(cb0, poff[j], j);
+#pragma unroll
+    for (int s = 0; s < BSTAGES - 1; ++s)
+        if (s < nsteps) issue_b(cb0 + s / 9, s % 9, s);
+
+    const int n_ss = (BSTAGES - 2) * (nb_wave + 1) + 1;               // steady-state count of younger DMAs
+    int s = 0;
+    for (int cb = cb0; cb < cb1; ++cb) {
+        const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
+        // keep the 9 x IM x 2 fragment addresses from being hoisted out of this loop as invariants (72 VGPRs, spills)
+#pragma unroll
+        for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const bool tail = s + BSTAGES - 1 >= nsteps;
+            if (tail) wait_vmcnt_dyn(0);
+            else if (s <= BSTAGES - 2) wait_vmcnt_dyn((BSTAGES - 2 - s) * nb_wave + s * (nb_wave + 1));
+            else wait_vmcnt_dyn(n_ss);
+            __builtin_amdgcn_s_barrier();
+            if (!tail) {
+                const int sn = s + BSTAGES - 1;                       // weight tile to issue: step sn = (cbn, tapn)
+                const int cbn = cb0 + sn / 9, tapn = sn - (sn / 9) * 9;
+                issue_b(cbn, tapn, sn % BSTAGES);
+                // next block's patch, one piece per tap (surplus taps re-issue piece 0: identical bytes)
+                if (tap < NPW && (tap * 8 + wave) * 8 < prows) issue_piece(cb + 1, poff[tap < NPW ? tap : 0], tap);
+                else issue_piece(cb + 1, poff[0], 0);
+            }
+            const unsigned char* sb = bring + (s % BSTAGES) * B_BYTES;
+            const int toff = (tap / 3) * W2 + (tap % 3);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[IM], bf[NJ];
+#pragma unroll
+                for (int i = 0; i < IM; ++i) {
+                    const int prow = prow0[i] + toff;
+                    af[i] = *reinterpret_cast<const bf16x8*>(pbuf + prow * 128 + (((fg + 4 * kk) ^ (prow & 7)) * 16));
+                }
+                const unsigned fch = kk ? fch1 : fch0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
+#pragma unroll
+                for (int i = 0; i < IM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);        // no cross-tap code motion: keeps fragment live ranges to one tap
+        }
+    }
+    ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM: C[m][n] += sum_k A(k,m) B(k,n) with BOTH operands reduction-major (k = pixel rows):
 // A = dY [P][M], B = X [P][N] (Linear) or the 3x3 gather of X (conv: column n = tap*Ci + c reads pixel src(p, tap)).
 // Same ring as above with [64 k][128 col] tiles (256-byte rows, a DMA piece = 4 k-rows); the MFMA operands are read
@@ -475,7 +637,7 @@ struct Config {
 // candidate table: the autotuner in gemm.hip times these per GEMM shape; ids are stable (plan cache values)
 static const Config kConfigs[] = {
     {256, 4, 3, 2}, {256, 5, 3, 2}, {128, 4, 4, 2}, {128, 5, 4, 2}, {64, 4, 6, 2}, {64, 5, 5, 2},
-    {128, 4, 2, 4}, {64, 4, 3, 4},  {64, 5, 2, 4},  {128, 6, 3, 2}, {64, 6, 4, 2},
+    {128, 4, 2, 4}, {64, 4, 3, 4},  {64, 5, 2, 4},  {128, 6, 3, 2}, {64, 6, 4, 2},  {128, 5, 2, 4},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -501,10 +663,46 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
 
 }  // namespace pdmk_ring
 
-int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs; }
+constexpr int kNumHalo = 4;      // halo-conv candidates follow the ring shapes in the candidate numbering
+static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
+    using namespace pdmk_ring;
+    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 1;
+    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return 1;
+    const int bm = id < 2 ? 256 : 128, nj = (id & 1) ? 4 : 5, pmax = id < 2 ? 400 : 264;
+    const int HW = g.conv_hi * g.conv_wi, W = g.conv_wi;
+    int prows;
+    if (HW >= bm) {
+        if ((HW % bm) || (bm % W)) return 1;
+        prows = (bm / W + 2) * (W + 2);
+    } else {
+        if (bm % HW) return 1;
+        prows = (bm / HW) * (g.conv_hi + 2) * (W + 2);
+    }
+    if (prows > pmax) return 1;
+    const int sk = g.splitk > 1 ? g.splitk : 1;
+    if (sk > (g.conv_ci + 63) / 64) return 1;
+    const int bn = 32 * nj;
+    dim3 grid(((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn), sk);
+    switch (id) {
+        case 0: hipLaunchKernelGGL((conv_halo_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
+        case 1: hipLaunchKernelGGL((conv_halo_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
+        case 2: hipLaunchKernelGGL((conv_halo_kernel<128, 5, 4, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
+        case 3: hipLaunchKernelGGL((conv_halo_kernel<128, 4, 5, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
+        default: return 1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs + kNumHalo; }
 int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demangled symbol rocprofv3 reports
     using namespace pdmk_ring;
-    if (id < 0 || id >= kNumConfigs) return -1;
+    if (id < 0 || id >= kNumConfigs + kNumHalo) return -1;
+    if (id >= kNumConfigs) {
+        const int h = id - kNumConfigs;
+        snprintf(buf, n, "pdmk_ring::conv_halo_kernel<%d, %d, %d, %d>", h < 2 ? 256 : 128, (h & 1) ? 4 : 5,
+                 h < 2 ? 3 : ((h & 1) ? 5 : 4), h < 2 ? 400 : 264);
+        return 0;
+    }
     const Config c = kConfigs[id];
     snprintf(buf, n, "pdmk_ring::igemm_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
     return 0;
@@ -521,7 +719,8 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     using namespace pdmk_ring;
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
-    if (id < 0 || id >= kNumConfigs) return 1;
+    if (id >= kNumConfigs) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumConfigs);
+    if (id < 0) return 1;
     const int sk = g.splitk > 1 ? g.splitk : 1;
     const Config c = kConfigs[id];
     const int bn = 32 * c.nj;
@@ -537,7 +736,7 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     switch (c.bm * 1000 + c.nj * 100 + c.stages * 10 + c.occ) {
         PDMK_RING_GO(256, 4, 3, 2) PDMK_RING_GO(256, 5, 3, 2) PDMK_RING_GO(128, 4, 4, 2) PDMK_RING_GO(128, 5, 4, 2)
         PDMK_RING_GO(64, 4, 6, 2) PDMK_RING_GO(64, 5, 5, 2) PDMK_RING_GO(128, 4, 2, 4) PDMK_RING_GO(64, 4, 3, 4)
-        PDMK_RING_GO(64, 5, 2, 4) PDMK_RING_GO(128, 6, 3, 2) PDMK_RING_GO(64, 6, 4, 2)
+        PDMK_RING_GO(64, 5, 2, 4) PDMK_RING_GO(128, 6, 3, 2) PDMK_RING_GO(64, 6, 4, 2) PDMK_RING_GO(128, 5, 2, 4)
         default: return 1;
     }
 #undef PDMK_RING_GO

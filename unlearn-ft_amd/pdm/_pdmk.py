@@ -74,6 +74,7 @@ _SIGS = {
     "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp, vp], i32),
     "pdmk_transpose_tiles": ([vp, vp, vp, i32, i32, vp], i32),
     "pdmk_sumsq": ([vp, i64, vp, i32, vp], i32),
+    "pdmk_zero": ([vp, i64, vp], i32),
     "pdmk_skinny_gemm": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_skinny_wgrad": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
 }
@@ -139,6 +140,24 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
 
 
+def zeros(shape, device, dtype):
+    """torch.zeros without a memset node (see pdmk_zero in include/pdmk.h); byte size padded to 16."""
+    n = 1
+    for d in shape:
+        n *= d
+    esz = torch.empty((), dtype=dtype).element_size()
+    pad = (-(n * esz)) % 16 // esz
+    flat = torch.empty(n + pad, device=device, dtype=dtype)
+    _chk(_lib.pdmk_zero(_p(flat), (n + pad) * esz, _st()), "pdmk_zero")
+    return flat[:n].view(*shape)
+
+
+def zero_(t):
+    assert t.is_contiguous() and (t.numel() * t.element_size()) % 16 == 0
+    _chk(_lib.pdmk_zero(_p(t), t.numel() * t.element_size(), _st()), "pdmk_zero")
+    return t
+
+
 def candidate_name(a_mode, b_mode, cand):
     buf = C.create_string_buffer(160)
     _chk(_lib.pdmk_gemm_candidate_name(a_mode, b_mode, cand, buf, 160), "pdmk_gemm_candidate_name")
@@ -184,7 +203,7 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
     if sk == 1:
         return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
                     a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs)
-    ws = torch.zeros((M, N), device=A.device, dtype=torch.float32)
+    ws = zeros((M, N), A.device, torch.float32)
     gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, macs=macs)
     _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b,
                                  int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")

@@ -145,6 +145,7 @@ class BilevelStepper:
                                     world) if bilevel else None
         self.reducer = GradReducer(student.store, bucket_mb)
         self.defer_reduce = False
+        self.segment_cb = None
         self._gscale = 1.0 / world
         # the frozen teacher pass and the student forward are independent until the loss heads: they run on two HIP
         # streams (two parallel branches once captured in a hipGraph) so the small-grid layers of one fill the CUs the
@@ -152,7 +153,7 @@ class BilevelStepper:
         # teacher forward on its own stream (independent of the student forward); PDMK_TEACHER_STREAM=0 runs it in line
         self.teacher_stream = (torch.cuda.Stream(device=self.dev) if os.environ.get("PDMK_TEACHER_STREAM", "1") != "0"
                                else None)
-        self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused)
+        self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # 32 bytes: zeroed by k.zero_   # diff, dist, block, (unused)
 
     # ------------------------------------------------------------------ pieces
     def _diffuse(self, latents, noise, timesteps, want_target):
@@ -182,8 +183,8 @@ class BilevelStepper:
                 k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
 
     def _backward_and_reduce(self):
-        if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between two graphs
-            self.student.engine.grad_ready_cb = None
+        if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between captured graphs
+            self.student.engine.grad_ready_cb = self.segment_cb      # None, or GraphedBilevel's capture-segment switch
             self.student.engine.backward()
             return 1.0 / self.world
         self.reducer.begin()
@@ -204,7 +205,7 @@ class BilevelStepper:
         need_teacher = w["block"] > 0 or w["dist"] > 0
         noisy, target = self._diffuse(latents, noise, timesteps, True)
         ehs = self._ehs2d(prompt_embeds)
-        self.losses.zero_()
+        k.zero_(self.losses)
         cur = torch.cuda.current_stream()
         ts = self.teacher_stream if self.teacher_stream is not None else cur
         if need_teacher:
@@ -220,7 +221,7 @@ class BilevelStepper:
         if w["dist"] > 0:
             k.mse_fwd(pred.t, pred_t.t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
         if backward:
-            pred.g = torch.zeros_like(pred.t)
+            pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
             k.mse_bwd(pred.t, target, wb, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["diff"] / n, False)
             if w["dist"] > 0:
                 k.mse_bwd(pred.t, pred_t.t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
@@ -241,7 +242,7 @@ class BilevelStepper:
         ehs2 = torch.cat([ehs, self._ehs2d(empty_prompt_embeds)], 0)
         noisy2 = torch.cat([noisy, noisy], 0)
         t2 = torch.cat([timesteps, timesteps], 0)
-        self.losses.zero_()
+        k.zero_(self.losses)
         cur = torch.cuda.current_stream()
         ts = self.teacher_stream if self.teacher_stream is not None else cur
         ts.wait_stream(cur)
@@ -255,7 +256,7 @@ class BilevelStepper:
         cp, n = pred.t.shape[1], M * C
         k.mse_fwd(pred.t, e_u, None, self.losses, 1, B, H * W, C, cp, cp, 1.0 / n)
         if backward:
-            pred.g = torch.zeros_like(pred.t)
+            pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
             k.mse_bwd(pred.t, e_u, None, pred.g, B, H * W, C, cp, cp, cp, 2.0 * w["up_dist"] / n, False)
         if w["up_block"] > 0:
             # the reference's teacher hooks hold the LAST teacher call (the unconditional one), trainer.py:2951-2954
@@ -302,7 +303,7 @@ class GraphedBilevel:
        Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
        with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
 
-    def __init__(self, stepper, B, C, H, W, T, ctx):
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6):
         self.st = stepper
         dev = stepper.dev
         self.lat = torch.zeros(B, C, H, W, device=dev)
@@ -311,6 +312,8 @@ class GraphedBilevel:
         self.ehs = torch.zeros(B, T, ctx, device=dev)
         self.empty = torch.zeros(B, T, ctx, device=dev)
         self.g_main = self.g_opt = self.g_upper = self.g_uopt = None
+        self.segments = segments
+        self.force_segments = False          # tests: cut the backward into segments on a single rank as well
 
     def _load(self, lat, noise, t, ehs, empty=None):
         self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
@@ -341,16 +344,13 @@ class GraphedBilevel:
                 st.upper_opt.launch(st._gscale)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_main = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
-            st.main_step(self.lat, self.noise, self.t, self.ehs)
+        self.g_main, self.main_offs = self._capture_step(lambda: st.main_step(self.lat, self.noise, self.t, self.ehs))
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             st.opt.launch(st._gscale)
         if bilevel:
-            self.g_upper = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_upper, capture_error_mode="thread_local"):
-                st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
+            self.g_upper, self.upper_offs = self._capture_step(
+                lambda: st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty))
             self.g_uopt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_uopt, capture_error_mode="thread_local"):
                 st.upper_opt.launch(st._gscale)
@@ -362,20 +362,58 @@ class GraphedBilevel:
         store.refresh()
         torch.cuda.synchronize()
 
+    def _capture_step(self, fn):
+        """Captures one step (forward + loss heads + backward).  One graph when there is nothing to exchange; with
+        world > 1 the backward is cut into `self.segments` graphs at block boundaries of the tape (equal shares of the
+        gradient arena), so that on replay the bucketed all-reduce of a finished share runs on the comm stream under
+        the next segment.  Returns ([graphs], [arena offset final after each graph])."""
+        st = self.st
+        nseg = self.segments if (st.world > 1 or self.force_segments) else 1
+        total = st.student.store.total
+        cuts = [total * (nseg - 1 - i) // nseg for i in range(nseg - 1)]      # descending arena offsets
+        graphs, offs = [torch.cuda.CUDAGraph()], []
+        cap_stream = torch.cuda.Stream()
+        cap_stream.wait_stream(torch.cuda.current_stream())
+
+        def seg_cb(off):
+            if len(offs) < len(cuts) and off <= cuts[len(offs)]:
+                graphs[-1].capture_end()
+                offs.append(off)
+                graphs.append(torch.cuda.CUDAGraph())
+                graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+
+        st.segment_cb = seg_cb if nseg > 1 else None
+        with torch.cuda.stream(cap_stream):
+            graphs[0].capture_begin(capture_error_mode="thread_local")
+            fn()
+            graphs[-1].capture_end()
+        offs.append(0)
+        st.segment_cb = None
+        torch.cuda.current_stream().wait_stream(cap_stream)
+        return graphs, offs
+
+    def _replay_step(self, graphs, offs):
+        st = self.st
+        if st.world == 1:
+            for g in graphs:
+                g.replay()
+            return
+        st.reducer.begin()
+        for g, off in zip(graphs, offs):
+            g.replay()
+            st.reducer.ready_down_to(off)        # comm stream waits for the segment just queued, then all-reduces its share
+        st.reducer.finish()
+
     def main(self, lat, noise, t, ehs):
         self._load(lat, noise, t, ehs)
-        self.g_main.replay()
-        if self.st.world > 1:
-            self.st.reduce_now()
+        self._replay_step(self.g_main, self.main_offs)
         lr = self.st.opt.prepare()
         self.g_opt.replay()
         return lr
 
     def upper(self, lat, noise, t, ehs, empty):
         self._load(lat, noise, t, ehs, empty)
-        self.g_upper.replay()
-        if self.st.world > 1:
-            self.st.reduce_now()
+        self._replay_step(self.g_upper, self.upper_offs)
         lr = self.st.upper_opt.prepare()
         self.g_uopt.replay()
         return lr
