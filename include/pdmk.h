@@ -74,6 +74,7 @@ typedef struct pdmk_gemm_args {
     int32_t accumulate;
     int32_t splitk;
     float alpha;
+    int32_t ldrv;        /* row stride of rowvec in floats; 0 = N (a column slice of one batched time-embedding projection) */
 } pdmk_gemm_args;
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
@@ -92,7 +93,8 @@ int pdmk_gemm_candidate_name(int a_mode, int b_mode, int id, char* buf, int n);
  * CUs): pdmk_gemm accumulated fp32 partials into the zeroed workspace ws[M,N] (out_f32, splitk>1); this applies the
  * epilogue C = (accumulate ? C : 0) + ws + bias + rowvec + R and stores in `dtype`. */
 int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
-                       int N, int ldc, int ldr, int rows_per_b, int accumulate, int dtype, pdmk_stream stream);
+                       int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int accumulate, int dtype,
+                       pdmk_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC.  Replaces F.group_norm + F.silu at blocks.py:318-319, 348+371,
@@ -153,8 +155,8 @@ int pdmk_copy2d(const void* src, void* dst, int64_t rows, int cols, int lds, int
 int pdmk_cast_permute(const float* src, void* dst, int n0, int n1, int n2, int mode, int dtype, pdmk_stream stream);
 /* column sums per batch: out[b*N + n] (+)= sum_{r<rows} x[(b*rows + r)*ld + n], b < nbatch  (bias gradients with
  * nbatch=1; gradient of the broadcast time-embedding add, blocks.py:334-341, with nbatch=B). out fp32. */
-int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch, int dtype,
-                pdmk_stream stream);
+int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch, int ldo /* out row
+                stride, 0 = N */, int dtype, pdmk_stream stream);
 /* backward of nearest x2 upsample: dst[b,y,x,c] = sum of the 2x2 block of src [B,2H,2W,C]. */
 int pdmk_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, int dtype, pdmk_stream stream);
 /* Timesteps(dim, flip_sin_to_cos=True, shift 0) (unet_2d_conditional.py:1514-1519): out[b] = [cos(t f_i), sin(t f_i)],

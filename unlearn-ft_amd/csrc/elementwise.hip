@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT) void transpose_tiles_kernel(const T* __restrict
 // atomic per column per block (blocks per batch are capped so same-address atomic contention stays low).
 template <typename T>
 __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int N,
-                                                    int ld, long rows_per_blk, int tpr) {
+                                                    int ld, long rows_per_blk, int tpr, int ldo) {
     constexpr int V = Vec<T>::N;
     __shared__ float red[NT * V];
     const int nc = N / V;
@@ -236,22 +236,23 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* __restrict__ x, flo
 #pragma unroll
             for (int e = 0; e < V; ++e) s[e] += red[(j * tpr + ct) * V + e];
 #pragma unroll
-        for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[(long)blockIdx.z * N + c * V + e], s[e]);
+        for (int e = 0; e < V; ++e) unsafeAtomicAdd(&out[(long)blockIdx.z * ldo + c * V + e], s[e]);
     }
 }
-__global__ void zero_f32_kernel(float* __restrict__ p, long n) {
+__global__ void zero_f32_kernel(float* __restrict__ p, long n, int N, int ldo) {      // [n / N rows][N cols], row stride ldo
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.f;
+    if (i < n) p[(i / N) * ldo + (i % N)] = 0.f;
 }
 template <typename T>
-int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nbatch, hipStream_t st) {
+int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nbatch, int ldo, hipStream_t st) {
+    if (ldo <= 0) ldo = N;
     constexpr int V = Vec<T>::N;
     if (N % V || ld % V) return -1;
     // a kernel, not hipMemsetAsync: memset nodes captured into the 2nd..nth hipGraph of a shared memory pool were seen to
     // leave the buffer unzeroed on replay (segmented backward graphs, ROCm 7.2)
     if (!acc) {
         const long n = (long)N * nbatch;
-        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n);
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n, N, ldo);
     }
     const int nc = N / V;
     int tpr = 1;
@@ -262,7 +263,7 @@ int colsum(const void* x, float* out, long rows, int N, int ld, int acc, int nba
     const long rpb = (rows + gy - 1) / gy;
     gy = (rows + rpb - 1) / rpb;
     hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, (int)gy, nbatch), dim3(NT), 0, st, (const T*)x, out, rows, N, ld, rpb,
-                       tpr);
+                       tpr, ldo);
     PDMK_CHECK_LAUNCH();
     return 0;
 }
@@ -414,7 +415,7 @@ __global__ void mse_bwd_kernel(const void* __restrict__ a, int adt, const void* 
 template <typename T>
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ C, const float* __restrict__ bias,
                                      const float* __restrict__ rowvec, const T* __restrict__ R, long M, int N, int ldc,
-                                     int ldr, int rows_per_b, int acc) {
+                                     int ldr, int rows_per_b, int ldrv, int acc) {
     const int nc = N / 4;
     const long total = M * nc;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -427,7 +428,7 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
             for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
         }
         if (rowvec) {
-            const float* rv = rowvec + (m / rows_per_b) * N + n;
+            const float* rv = rowvec + (m / rows_per_b) * ldrv + n;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += rv[e];
         }
@@ -548,10 +549,10 @@ extern "C" int pdmk_zero(void* p, int64_t nbytes, pdmk_stream s) {
     return 0;
 }
 
-extern "C" int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch,
+extern "C" int pdmk_colsum(const void* x, float* out, int64_t rows, int N, int ld, int accumulate, int nbatch, int ldo,
                            int dtype, pdmk_stream s) {
     if (!x || !out || rows <= 0 || N <= 0 || nbatch <= 0) return -1;
-    PDMK_DISPATCH(dtype, colsum, x, out, (long)rows, N, ld, accumulate, nbatch, (hipStream_t)s);
+    PDMK_DISPATCH(dtype, colsum, x, out, (long)rows, N, ld, accumulate, nbatch, ldo, (hipStream_t)s);
 }
 extern "C" int pdmk_pool2x2_sum(const void* src, void* dst, int B, int H, int W, int C, int dtype, pdmk_stream s) {
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
@@ -631,16 +632,17 @@ extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, con
     return 0;
 }
 extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R,
-                                  int64_t M, int N, int ldc, int ldr, int rows_per_b, int accumulate, int dtype,
+                                  int64_t M, int N, int ldc, int ldr, int rows_per_b, int ldrv, int accumulate, int dtype,
                                   pdmk_stream s) {
     if (!ws || !C || M <= 0 || N <= 0 || (N & 3) || (rowvec && rows_per_b <= 0)) return -1;
+    if (ldrv <= 0) ldrv = N;
     dim3 grid(grid_for(M * (N / 4)));
     if (dtype == PDMK_BF16)
         hipLaunchKernelGGL(splitk_finish_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, ws, (bf16*)C, bias, rowvec,
-                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, accumulate);
+                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, accumulate);
     else if (dtype == PDMK_F32)
         hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
-                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, accumulate);
+                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, accumulate);
     else return -2;
     PDMK_CHECK_LAUNCH();
     return 0;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
                         float v = stage[lrow * SROW + h * 64 + lane];
                         if (first) {
                             if (g.bias) v += g.bias[n];
-                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) + n];
                             if (Rp) v += to_f32(Rp[(long)m * g.ldr + n]);
                         }
                         unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
             const int lrow = tid / TPS, seg = (tid % TPS) * SEG;
             const int m = m0 + pass * 64 + lrow;
             if (m < g.M) {
-                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) : nullptr;
 #pragma unroll
                 for (int c8 = 0; c8 < SEG / 8; ++c8) {
                     const int n = n0 + seg + c8 * 8;
@@ -624,19 +624,23 @@ float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws,
             if (hipMemsetAsync(ws, 0, (size_t)a.M * a.N * 4, st) != hipSuccess) return -1;
             const int rc = launch_candidate(a, st, id);
             if (rc) return rc;
-            return pdmk_splitk_finish(ws, fin_out, nullptr, nullptr, nullptr, a.M, a.N, a.N, 0, 1, 0, a.dtype, st);
+            return pdmk_splitk_finish(ws, fin_out, nullptr, nullptr, nullptr, a.M, a.N, a.N, 0, 1, 0, 0, a.dtype, st);
         }
         return launch_candidate(a, st, id);
     };
     if (once() != 0) { (void)hipGetLastError(); return 1e30f; }
-    (void)hipEventRecord(e0, st);
-    for (int r = 0; r < reps; ++r)
-        if (once() != 0) { (void)hipGetLastError(); return 1e30f; }
-    (void)hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    return ms * 1000.f / reps;
+    float best = 1e30f;
+    for (int round = 0; round < 2; ++round) {        // two rounds, keep the faster: one-off stalls must not pick the plan
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r)
+            if (once() != 0) { (void)hipGetLastError(); return 1e30f; }
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    return best * 1000.f / reps;
 }
 
 // best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().

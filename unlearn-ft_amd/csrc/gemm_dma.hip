@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
                         float v = stage[lr2 * SROW + h * 64 + lane];
                         if (first) {
                             if (g.bias) v += g.bias[n];
-                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) + n];
                             if (Rp) v += (float)Rp[(long)m * g.ldr + n];
                         }
                         unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
             const int lr2 = tid >> 3, seg = (tid & 7) * 16;
             const int m = m0 + pass * 64 + lr2;
             if (m < g.M) {
-                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) : nullptr;
 #pragma unroll
                 for (int c8 = 0; c8 < 2; ++c8) {
                     const int n = n0 + seg + c8 * 8;

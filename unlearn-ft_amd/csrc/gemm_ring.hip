@@ -97,7 +97,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                         float v = stage[lr2 * SROW + cl];
                         if (first) {
                             if (g.bias) v += g.bias[n];
-                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * g.N + n];
+                            if (g.rowvec) v += g.rowvec[(long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) + n];
                             if (Rp) v += (float)Rp[(long)m * g.ldr + n];
                         }
                         unsafeAtomicAdd(Cf + (long)m * g.ldc + n, v);
@@ -134,7 +134,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
                 if (g.rowvec) {
-                    const float* rv = g.rowvec + (long)(m / g.rows_per_b) * g.N + n;
+                    const float* rv = g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) + n;
                     const float4 b0 = *reinterpret_cast<const float4*>(rv), b1 = *reinterpret_cast<const float4*>(rv + 4);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
                 const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
                 if (m >= g.M || n >= g.N) continue;
-                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * g.N : nullptr;
+                const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) : nullptr;
                 const long off = (long)m * g.ldc + n;
                 const int nv = min(8, g.N - n);
                 for (int r = 0; r < nv; ++r) {

@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
                 ("rows_per_b", i32), ("a_mode", i32), ("b_mode", i32),
                 ("conv_b", i32), ("conv_hi", i32), ("conv_wi", i32), ("conv_ci", i32), ("conv_ho", i32),
                 ("conv_wo", i32), ("conv_mode", i32), ("conv_ld", i32),
-                ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32)]
+                ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32), ("ldrv", i32)]
 
 
 _SIGS = {
@@ -48,7 +48,7 @@ _SIGS = {
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
     "pdmk_gemm_last_candidate": ([], i32),
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
-    "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
@@ -62,7 +62,7 @@ _SIGS = {
     "pdmk_silu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
     "pdmk_copy2d": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_cast_permute": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    "pdmk_colsum": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_colsum": ([vp, vp, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_pool2x2_sum": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_timestep_embed": ([vp, vp, vp, i32, i32, i32, vp], i32),
     "pdmk_add_noise_velocity": ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
@@ -115,7 +115,7 @@ PROFILE = None   # bench.py sets this to a list: every gemm launch is then brack
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
-         macs=None, colsum_out=None):
+         macs=None, colsum_out=None, ldrv=0):
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
     g.colsum_out = _p(colsum_out)
@@ -123,7 +123,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     g.bias, g.rowvec, g.R = _p(bias), _p(rowvec), _p(R)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc, g.ldr = lda, ldb, ldc, ldr
-    g.rows_per_b = rows_per_b
+    g.rows_per_b, g.ldrv = rows_per_b, ldrv
     g.a_mode, g.b_mode = a_mode, b_mode
     if conv is not None:
         (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
@@ -197,15 +197,15 @@ def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None):
 
 
 def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
-              a_mode=A_ROWK, conv=None, accumulate=False, macs=None):
+              a_mode=A_ROWK, conv=None, accumulate=False, macs=None, ldrv=0):
     """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace."""
     sk = splitk_plan(A, B, M, N, K, lda, ldb, a_mode, conv)
     if sk == 1:
         return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
-                    a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs)
+                    a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs, ldrv=ldrv)
     ws = zeros((M, N), A.device, torch.float32)
     gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, macs=macs)
-    _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b,
+    _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv,
                                  int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")
 
 
@@ -281,8 +281,8 @@ def cast_permute(src, dst, n0, n1, n2, mode):
     _chk(_lib.pdmk_cast_permute(_p(src), _p(dst), n0, n1, n2, mode, dt(dst), _st()), "pdmk_cast_permute")
 
 
-def colsum(x, out, rows, N, ld, accumulate=False, nbatch=1):
-    _chk(_lib.pdmk_colsum(_p(x), _p(out), rows, N, ld, int(accumulate), nbatch, dt(x), _st()), "pdmk_colsum")
+def colsum(x, out, rows, N, ld, accumulate=False, nbatch=1, ldo=0):
+    _chk(_lib.pdmk_colsum(_p(x), _p(out), rows, N, ld, int(accumulate), nbatch, ldo, dt(x), _st()), "pdmk_colsum")
 
 
 def skinny_gemm(x, w, y, M, N, K, ldx, ldw, ldy, bias=None, accumulate=False):

@@ -13,7 +13,7 @@ import os
 import torch
 
 from ... import _pdmk as k
-from .params import ParamStore
+from .params import ParamStore, temb_layout
 from .spec import UNetConfig, padc
 
 
@@ -44,6 +44,7 @@ class UNetEngine:
         self.grad_ready_cb = None      # called with an arena offset: every gradient at or beyond it is final
         # weight-gradient GEMMs only feed the optimiser: they run on a side stream (a parallel branch of the captured
         # graph) next to the dgrad chain, which is the critical path of the backward pass
+        self.temb_lay, self.temb_cols = temb_layout(cfg, blocks)
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -105,8 +106,10 @@ class UNetEngine:
         M = x.t.shape[0]
         assert x.t.shape[1] == Kp, f"{key}: input has {x.t.shape[1]} cols, weight expects {Kp}"
         y = self._empty(M, Np, torch.float32 if out_f32 else None)
-        skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * max(Kp, Np) * 4 + 512 <= 65536
-        if skinny:          # time-embedding MLP / time_emb_proj: M = batch rows -> weight-streaming kernel
+        # time-embedding MLP / batched time_emb_proj: M = batch rows -> weight-streaming kernels (skinny operand in LDS)
+        skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * Kp * 4 + 512 <= 65536
+        skinny_dgrad = skinny and (8 if M <= 8 else 16) * Np * 4 + 512 <= 65536
+        if skinny:
             k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None)
         else:
             (k.gemm if out_f32 else k.gemm_auto)(
@@ -124,9 +127,16 @@ class UNetEngine:
                     xt = x.t
                     k.skinny_wgrad(dy, xt, P.g(key + ".weight"), P.g(bias) if bias else None, M, Np, Kp, _ld(dy),
                                    _ld(xt), Kp)
-                    if x.rg:
+                    if x.rg and skinny_dgrad:
                         dx, acc = self._grad_into(x, M, Kp)
                         k.skinny_gemm(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc)
+                    elif x.rg:            # wide projection (all time_emb_proj at once): dy does not fit LDS -> tiled GEMM
+                        dyc = dy
+                        if dy.dtype != self.dtype:
+                            dyc = self._empty(M, Np)
+                            k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
+                        dx, acc = self._grad_into(x, M, Kp)
+                        k.gemm_auto(dyc, P.wtv(key + ".weight"), dx, M, Kp, Np, Np, Np, _ld(dx), accumulate=acc, macs=lmacs)
                     return
                 if dy.dtype != self.dtype:        # fp32 output (time-embedding projections): tiny cast for the GEMMs
                     dyc = self._empty(M, Np)
@@ -150,8 +160,10 @@ class UNetEngine:
             self.tape.append(bwd)
         return out
 
-    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None):
-        """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather."""
+    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None):
+        """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather.
+        rowvec (+ rv_cols = (first column, width)): per-image row added to every pixel = this ResBlock's column slice of
+        the batched time-embedding projection [B, sum of widths] (fp32)."""
         P = self.P
         e = P.by_key[key + ".weight"]
         Cop, _, Cip = e.shape
@@ -161,7 +173,8 @@ class UNetEngine:
         y = self._empty(M, Cop)
         k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
-               rowvec=rowvec.t if rowvec is not None else None, rows_per_b=Ho * Wo,
+               rowvec=rowvec.t[:, rv_cols[0]:] if rowvec is not None else None, rows_per_b=Ho * Wo,
+               ldrv=_ld(rowvec.t) if rowvec is not None else 0,
                R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
                macs=M * e.logical[0] * e.logical[1] * 9)
         lmacs = M * e.logical[0] * e.logical[1] * 9
@@ -194,12 +207,14 @@ class UNetEngine:
                                     a_mode=k.A_CONV, conv=(B, Ho, Wo, Cop, Hi, Wi, 3 if mode == 1 else 0, ldy),
                                accumulate=acc, macs=lmacs)
                 if rowvec is not None:
-                    # d(rowvec)[b] = column sums of dy over the pixels of image b; conv bias grad = their sum over b
-                    dtp = torch.empty((B, Cop), device=self.dev, dtype=torch.float32)
+                    # d(rowvec)[b] = column sums of dy over the pixels of image b, written into this block's column slice
+                    # of the batched projection's gradient; conv bias grad = their sum over b
+                    if rowvec.g is None:
+                        rowvec.g = k.zeros(tuple(rowvec.t.shape), self.dev, torch.float32)
+                    dtp = rowvec.g[:, rv_cols[0]:]
                     hw = Ho * Wo
-                    k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B)
-                    k.colsum(dtp, P.g(bias), B, Cop, Cop, accumulate=True)
-                    rowvec.g = dtp
+                    k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B, ldo=_ld(rowvec.g))
+                    k.colsum(dtp, P.g(bias), B, Cop, _ld(rowvec.g), accumulate=True)
                 if residual is not None:
                     self._wgrad_fence()
                     self._give(residual, dy)
@@ -327,8 +342,7 @@ class UNetEngine:
         p = r.name
         self._mark(p + ".norm1.weight")
         n1 = self.groupnorm(x, p + ".norm1", B, H * W, G, r.cin // G, 1e-5, True)
-        tp = self.linear(st, p + ".time_emb_proj", bias=p + ".time_emb_proj.bias", out_f32=True)
-        h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=tp)
+        h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=st, rv_cols=self.temb_lay[p][:2])
         n2 = self.groupnorm(h1, p + ".norm2", B, H * W, r.groups2(G), r.cout // G, 1e-5, True)
         res = x if r.cin == r.cout else self.linear(x, p + ".conv_shortcut", bias=p + ".conv_shortcut.bias")
         out, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res)
@@ -374,6 +388,8 @@ class UNetEngine:
         e1 = self.linear(Act(te, rg=False), "time_embedding.linear_1", bias="time_embedding.linear_1.bias")
         temb = self.linear(self.silu(e1), "time_embedding.linear_2", bias="time_embedding.linear_2.bias")
         st = self.silu(temb)                      # shared by every ResBlock (blocks.py:336)
+        if self.temb_cols:                        # all time_emb_proj in one skinny GEMM; ResBlocks take column slices
+            st = self.linear(st, "time_emb_proj_all", bias="time_emb_proj_all.bias", out_f32=True)
         ehs_act = Act(ehs, rg=False)
         h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias")
         skips = [h]

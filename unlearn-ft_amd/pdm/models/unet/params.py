@@ -68,6 +68,18 @@ def _geglu_rows(name, ff):
     return [(name, ff, 0, 0), (name, ff, padc(ff), ff)]
 
 
+def temb_layout(cfg: UNetConfig, blocks):
+    """Column layout of the ONE batched time-embedding projection (all ResBlocks' time_emb_proj, blocks.py:334-341, share
+    the input silu(temb)): {resblock name: (first column, padded width)} in forward order, and the total width."""
+    G, off, lay = cfg.norm_num_groups, 0, {}
+    for b in blocks:
+        for r in b.resnets:
+            if not r.dropped:
+                lay[r.name] = (off, padc(r.inner(G)), r.inner(G))
+                off += padc(r.inner(G))
+    return lay, off
+
+
 def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
     G = cfg.norm_num_groups
     E: List[Entry] = []
@@ -76,6 +88,13 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
     for nm, (ki, no) in (("time_embedding.linear_1", (c0, cfg.temb_dim)),
                          ("time_embedding.linear_2", (cfg.temb_dim, cfg.temb_dim))):
         E += [_lin(nm, [(nm + ".weight", no)], ki), _vec(nm + ".bias", [(nm + ".bias", no)])]
+    # every ResBlock's time_emb_proj as row blocks of one weight / bias: one GEMM forward, one dgrad, one wgrad per step
+    lay, tot = temb_layout(cfg, blocks)
+    if tot:
+        E += [_lin("time_emb_proj_all", [(f"{n}.time_emb_proj.weight", ci, o, 0) for n, (o, cp, ci) in lay.items()],
+                   cfg.temb_dim, rows_p=tot),
+              _vec("time_emb_proj_all.bias", [(f"{n}.time_emb_proj.bias", ci, o, 0) for n, (o, cp, ci) in lay.items()],
+                   rows_p=tot)]
 
     def res_entries(r):
         if r.dropped:
@@ -84,8 +103,6 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
         out = [_vec(f"{p}.norm1.weight", [(f"{p}.norm1.weight", r.cin)]),
                _vec(f"{p}.norm1.bias", [(f"{p}.norm1.bias", r.cin)]),
                _conv(f"{p}.conv1", ci, r.cin), _vec(f"{p}.conv1.bias", [(f"{p}.conv1.bias", ci)]),
-               _lin(f"{p}.time_emb_proj", [(f"{p}.time_emb_proj.weight", ci)], cfg.temb_dim),
-               _vec(f"{p}.time_emb_proj.bias", [(f"{p}.time_emb_proj.bias", ci)]),
                _vec(f"{p}.norm2.weight", [(f"{p}.norm2.weight", ci)]),
                _vec(f"{p}.norm2.bias", [(f"{p}.norm2.bias", ci)]),
                _conv(f"{p}.conv2", r.cout, ci), _vec(f"{p}.conv2.bias", [(f"{p}.conv2.bias", r.cout)])]
@@ -139,7 +156,7 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
     off = 0
     for e in E:
         e.off = off
-        off += (e.numel + 7) // 8 * 8
+        off += (e.numel + 127) // 128 * 128          # every entry starts on a 256-byte (bf16) / 512-byte (fp32) boundary
     return E
 
 
@@ -149,7 +166,7 @@ class ParamStore:
     def __init__(self, entries: List[Entry], device, dtype, train=True):
         self.entries = entries
         self.by_key = {e.key: e for e in entries}
-        self.total = entries[-1].off + (entries[-1].numel + 7) // 8 * 8
+        self.total = entries[-1].off + (entries[-1].numel + 127) // 128 * 128
         self.dtype = dtype
         self.train = train
         self.master = torch.zeros(self.total, device=device, dtype=torch.float32)
