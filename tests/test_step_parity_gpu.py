@@ -230,7 +230,7 @@ def test_segmented_graph_replay_matches_eager(dev):
     ref = student.store.grad.clone()
     ref_loss = st.losses.clone()
     for nseg in (1, 4):
-        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg)
+        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False)
         g.force_segments = nseg > 1
         g.capture(bilevel=False)
         assert len(g.g_main) == nseg, (len(g.g_main), g.main_offs)
@@ -241,3 +241,40 @@ def test_segmented_graph_replay_matches_eager(dev):
         assert torch.allclose(st.losses, ref_loss, rtol=5e-3, atol=1e-6)       # split-K atomics: not bit-reproducible
         rel = (student.store.grad - ref).abs().max().item() / ref.abs().max().item()
         assert rel < 2e-2, (nseg, rel)       # split-K atomics order differs between launches; bf16 path
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_streamed_adamw_matches_step_then_optimizer(dev, forced):
+    """Graph mode applies AdamW to every finished sixth of the gradient arena while the backward is still running (and,
+    with several ranks, behind that share's all-reduce); parameters and moments after two iterations must equal
+    backward-then-optimiser.  forced=True exercises the multi-graph (N > 1) replay path on one rank."""
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
+    lat, noise, t, ehs, _ = _inputs()
+    lat, noise, t, ehs = lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda()
+    results = []
+    for mode in ("eager", "graph"):
+        ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16)
+        st = BilevelStepper(student, teacher, lr=1e-3, upper_lr=1e-3)
+        if mode == "graph":
+            g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=4, stream_opt=True)
+            g.force_segments = forced
+            g.capture(bilevel=False)
+        for _ in range(2):
+            if mode == "eager":
+                st.main_step(lat, noise, t, ehs)
+                st.optimizer_step()
+            else:
+                g.main(lat, noise, t, ehs)
+        torch.cuda.synchronize()
+        assert float(student.store.grad.abs().max()) == 0.0
+        results.append((student.store.master.clone(), st.opt.m.clone(), student.store.w.float().clone(),
+                        student.store.wt.float().clone()))
+    # Adam's first steps move every weight by ~lr whatever the gradient size, so a near-zero gradient whose sign flips
+    # with the split-K atomics order moves a weight by 2 lr per step: bound the worst element by that, and the mean tightly
+    for a, b, what in zip(results[0], results[1], ("master", "exp_avg", "bf16 copy", "transposed copy")):
+        d = (a - b).abs()
+        if what == "exp_avg":
+            assert d.max().item() <= 2e-2 * a.abs().max().item(), (what, d.max().item())
+        else:
+            assert d.max().item() <= 4.2e-3 + 1e-2 * a.abs().max().item() * (what != "master"), (what, d.max().item())
+        assert d.mean().item() <= 2e-3 * a.abs().mean().item() + 1e-6, (what, d.mean().item(), a.abs().mean().item())

@@ -60,6 +60,16 @@ class FusedAdamW:
                 self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
         s.refresh(w_is_fresh=fused)
 
+    def launch_range(self, lo, hi, grad_scale=1.0, zero_grad=True):
+        """AdamW on arena slice [lo, hi) only (no refresh of the transposed copies): lets the update of layers whose
+        gradients are final stream under the rest of the backward pass (HBM-bound kernel beside MFMA-bound ones)."""
+        if hi <= lo:
+            return
+        s = self.store
+        fused = s.dtype == torch.bfloat16
+        k.adamw(s.master[lo:hi], s.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], hi - lo, self.lr_dev, self.betas[0],
+                self.betas[1], self.eps, self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w[lo:hi] if fused else None)
+
     def step(self, grad_scale=1.0, zero_grad=True):
         lr = self.prepare()
         self.launch(grad_scale, zero_grad)
@@ -303,7 +313,7 @@ class GraphedBilevel:
        Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
        with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
 
-    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6):
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True):
         self.st = stepper
         dev = stepper.dev
         self.lat = torch.zeros(B, C, H, W, device=dev)
@@ -314,6 +324,10 @@ class GraphedBilevel:
         self.g_main = self.g_opt = self.g_upper = self.g_uopt = None
         self.segments = segments
         self.force_segments = False          # tests: cut the backward into segments on a single rank as well
+        # AdamW of every finished sixth of the arena runs beside the rest of the backward (valid without gradient-norm
+        # clipping, which needs all gradients first; the shipped configs do not clip: trainer.py:2784-2786)
+        self.stream_opt = stream_opt
+        self.opt_stream = torch.cuda.Stream(device=dev)
 
     def _load(self, lat, noise, t, ehs, empty=None):
         self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
@@ -344,13 +358,13 @@ class GraphedBilevel:
                 st.upper_opt.launch(st._gscale)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_main, self.main_offs = self._capture_step(lambda: st.main_step(self.lat, self.noise, self.t, self.ehs))
+        self.g_main, self.main_offs = self._capture_step(lambda: st.main_step(self.lat, self.noise, self.t, self.ehs), st.opt)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             st.opt.launch(st._gscale)
         if bilevel:
             self.g_upper, self.upper_offs = self._capture_step(
-                lambda: st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty))
+                lambda: st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty), st.upper_opt)
             self.g_uopt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_uopt, capture_error_mode="thread_local"):
                 st.upper_opt.launch(st._gscale)
@@ -362,58 +376,92 @@ class GraphedBilevel:
         store.refresh()
         torch.cuda.synchronize()
 
-    def _capture_step(self, fn):
-        """Captures one step (forward + loss heads + backward).  One graph when there is nothing to exchange; with
-        world > 1 the backward is cut into `self.segments` graphs at block boundaries of the tape (equal shares of the
-        gradient arena), so that on replay the bucketed all-reduce of a finished share runs on the comm stream under
-        the next segment.  Returns ([graphs], [arena offset final after each graph])."""
+    def _capture_step(self, fn, opt):
+        """Captures one step (forward + loss heads + backward [+ streamed AdamW]).  The tape is cut at block boundaries into
+        `self.segments` equal shares of the gradient arena (descending offsets).  world == 1: one graph; at every cut the
+        AdamW of the finished share is forked onto `opt_stream` (a parallel branch of the graph).  world > 1: one graph per
+        share, so that on replay the bucketed all-reduce (and then the AdamW) of a finished share runs on the comm stream
+        under the next segment.  Returns ([graphs], [arena offset final after each graph])."""
         st = self.st
-        nseg = self.segments if (st.world > 1 or self.force_segments) else 1
-        total = st.student.store.total
+        multi = st.world > 1 or self.force_segments
+        nseg = self.segments if (multi or self.stream_opt) else 1
+        store = st.student.store
+        total = store.total
         cuts = [total * (nseg - 1 - i) // nseg for i in range(nseg - 1)]      # descending arena offsets
         graphs, offs = [torch.cuda.CUDAGraph()], []
         cap_stream = torch.cuda.Stream()
         cap_stream.wait_stream(torch.cuda.current_stream())
+        state = {"hi": total, "n": 0}
+
+        def fork_adamw(lo):
+            self.opt_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.opt_stream):
+                opt.launch_range(lo, state["hi"], st._gscale)
+            state["hi"] = lo
 
         def seg_cb(off):
-            if len(offs) < len(cuts) and off <= cuts[len(offs)]:
-                graphs[-1].capture_end()
-                offs.append(off)
-                graphs.append(torch.cuda.CUDAGraph())
-                graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+            if state["n"] < len(cuts) and off <= cuts[state["n"]]:
+                state["n"] += 1
+                if multi:
+                    graphs[-1].capture_end()
+                    offs.append(off)
+                    graphs.append(torch.cuda.CUDAGraph())
+                    graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+                elif self.stream_opt:
+                    fork_adamw(off)
 
         st.segment_cb = seg_cb if nseg > 1 else None
         with torch.cuda.stream(cap_stream):
             graphs[0].capture_begin(capture_error_mode="thread_local")
             fn()
+            if self.stream_opt and not multi:
+                fork_adamw(0)
+                torch.cuda.current_stream().wait_stream(self.opt_stream)
+                store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
             graphs[-1].capture_end()
         offs.append(0)
         st.segment_cb = None
         torch.cuda.current_stream().wait_stream(cap_stream)
         return graphs, offs
 
-    def _replay_step(self, graphs, offs):
+    def _replay_step(self, graphs, offs, opt=None):
+        """opt: the optimiser to stream (None = gradients only, the caller applies the optimiser)."""
         st = self.st
+        store = st.student.store
         if st.world == 1:
             for g in graphs:
                 g.replay()
+            if opt is not None and self.stream_opt and len(graphs) > 1:      # forced segments on one rank (tests)
+                opt.launch_range(0, store.total, st._gscale)
+                store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
             return
-        st.reducer.begin()
+        red = st.reducer
+        red.begin()
+        done = store.total                       # AdamW has been issued for [done, total)
         for g, off in zip(graphs, offs):
             g.replay()
-            st.reducer.ready_down_to(off)        # comm stream waits for the segment just queued, then all-reduces its share
-        st.reducer.finish()
+            red.ready_down_to(off)               # comm stream waits for the segment just queued, then all-reduces its share
+            if opt is not None and self.stream_opt and red.stream is not None and red.next_hi < done:
+                with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind it
+                    opt.launch_range(red.next_hi, done, st._gscale)
+                done = red.next_hi
+        red.finish()
+        if opt is not None and self.stream_opt:
+            opt.launch_range(0, done, st._gscale)
+            store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
 
     def main(self, lat, noise, t, ehs):
+        lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches inside the step
         self._load(lat, noise, t, ehs)
-        self._replay_step(self.g_main, self.main_offs)
-        lr = self.st.opt.prepare()
-        self.g_opt.replay()
+        self._replay_step(self.g_main, self.main_offs, self.st.opt)
+        if not self.stream_opt:
+            self.g_opt.replay()
         return lr
 
     def upper(self, lat, noise, t, ehs, empty):
-        self._load(lat, noise, t, ehs, empty)
-        self._replay_step(self.g_upper, self.upper_offs)
         lr = self.st.upper_opt.prepare()
-        self.g_uopt.replay()
+        self._load(lat, noise, t, ehs, empty)
+        self._replay_step(self.g_upper, self.upper_offs, self.st.upper_opt)
+        if not self.stream_opt:
+            self.g_uopt.replay()
         return lr
