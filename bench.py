@@ -215,7 +215,12 @@ def main():
                 r[2] += 1
         class_names = {(0, 0): "linear fwd/dgrad", (1, 0): "conv3x3 fwd/dgrad (implicit GEMM)",
                        (2, 1): "linear wgrad", (2, 2): "conv3x3 wgrad"}
-        sym = lambda kd: k.candidate_name(kd[1], kd[2], kd[3])
+        # candidate 0 = the K-step-32 kernels; rocprofv3's demangler garbles `igemm_kernel<__bf16, a, b, c, 8, 8>`, so the
+        # strings it prints for the two weight-gradient instantiations are kept here to look their PMC traffic up
+        legacy_sym = {(2, 1): "igemm_kernel<bool _Accum, int, EL, int, E, 0, 8, 8>",
+                      (2, 2): "_ZN12_GLOBAL__N_112igemm_kernelIDF16bLi2ELi2ELi0ELi8ELi8EEEv14pdmk_gemm_argsiijj"}
+        sym = lambda kd: (k.candidate_name(kd[1], kd[2], kd[3]) if kd[3] > 0 else
+                          f"igemm_kernel<__bf16, {kd[1]}, {kd[2]}, 0, 8, 8> [rocprofv3: {legacy_sym.get(kd[1:3], 'igemm_kernel / pdmk_dma::igemm_dma_kernel')}]")
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
         peak = 2500.0 if a.dtype == "bf16" else 157.3
@@ -224,7 +229,7 @@ def main():
         if os.path.exists(tfile) and not a.tiny:
             # HBM bytes per launch of this kernel symbol from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
             # this same command (tools/summarize_pmc.py; gfx950 2x FETCH_SIZE correction applied); counters cannot be read live
-            rec = json.load(open(tfile)).get(sym(dom[0]))
+            rec = json.load(open(tfile)).get(sym(dom[0]) if dom[0][3] > 0 else legacy_sym.get(dom[0][1:3], ""))
             traffic = rec and round(rec["hbm_bytes_per_launch"])
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]
         roof = {"bound": "mfma", "kernel": sym(dom[0]), "kernel_class": class_names[dom[0][1:3]],

@@ -71,7 +71,9 @@ typedef struct pdmk_gemm_args {
     int32_t conv_b, conv_hi, conv_wi, conv_ci, conv_ho, conv_wo, conv_mode, conv_ld;
     int32_t dtype;       /* PDMK_F32 | PDMK_BF16: type of A, B, R and (unless out_f32) C */
     int32_t out_f32;
-    int32_t accumulate;
+    int32_t accumulate;  /* 0: C = result; 1: C += result; 2 ("slab", needs out_f32 and splitk > 1, no bias/rowvec/R): C is a
+                            [splitk][M][ldc] fp32 workspace and split z stores its partial into slab z with plain stores
+                            (no atomics, no zero-fill, bit-reproducible); pdmk_splitk_finish adds the slabs */
     int32_t splitk;
     float alpha;
     int32_t ldrv;        /* row stride of rowvec in floats; 0 = N (a column slice of one batched time-embedding projection) */
@@ -89,12 +91,13 @@ int pdmk_gemm_plan(const pdmk_gemm_args* args, pdmk_stream stream, int32_t* spli
  * PDMK_PLAN_CACHE=<file> persists the plan cache across processes; PDMK_GEMM_TUNE=0 disables on-device tuning. */
 int pdmk_gemm_last_candidate(void);
 int pdmk_gemm_candidate_name(int a_mode, int b_mode, int id, char* buf, int n);
-/* Second half of a split-K forward/dgrad GEMM (small-M layers at 8x8 / 16x16 latents: too few output tiles to fill 256
- * CUs): pdmk_gemm accumulated fp32 partials into the zeroed workspace ws[M,N] (out_f32, splitk>1); this applies the
- * epilogue C = (accumulate ? C : 0) + ws + bias + rowvec + R and stores in `dtype`. */
+/* Second half of a split-K GEMM (small-M layers at 8x8 / 16x16 latents, every weight gradient: too few output tiles
+ * to fill 256 CUs): pdmk_gemm left fp32 partials in ws - `nslab` slabs [nslab][M][N] written with accumulate = 2, or one
+ * zero-initialised [M][N] image accumulated with atomics (nslab = 1); this adds the slabs in a fixed order and applies the
+ * epilogue C = (accumulate ? C : 0) + sum(ws) + bias + rowvec + R, stored in `dtype` (PDMK_F32 for weight gradients). */
 int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
-                       int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int accumulate, int dtype,
-                       pdmk_stream stream);
+                       int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int nslab /* slabs in ws */,
+                       int accumulate, int dtype, pdmk_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC.  Replaces F.group_norm + F.silu at blocks.py:318-319, 348+371,

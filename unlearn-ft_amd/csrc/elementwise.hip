@@ -415,13 +415,17 @@ __global__ void mse_bwd_kernel(const void* __restrict__ a, int adt, const void* 
 template <typename T>
 __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict__ C, const float* __restrict__ bias,
                                      const float* __restrict__ rowvec, const T* __restrict__ R, long M, int N, int ldc,
-                                     int ldr, int rows_per_b, int ldrv, int acc) {
+                                     int ldr, int rows_per_b, int ldrv, int nslab, int acc) {
     const int nc = N / 4;
     const long total = M * nc;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const long m = i / nc;
         const int n = (int)(i - m * nc) * 4;
-        const float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
+        float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
+        for (int sl = 1; sl < nslab; ++sl) {                       // split-K slabs [nslab][M][N], added in a fixed order
+            const float4 u = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * N + n);
+            w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
+        }
         float v[4] = {w.x, w.y, w.z, w.w};
         if (bias) {
 #pragma unroll
@@ -632,17 +636,17 @@ extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, con
     return 0;
 }
 extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R,
-                                  int64_t M, int N, int ldc, int ldr, int rows_per_b, int ldrv, int accumulate, int dtype,
-                                  pdmk_stream s) {
-    if (!ws || !C || M <= 0 || N <= 0 || (N & 3) || (rowvec && rows_per_b <= 0)) return -1;
+                                  int64_t M, int N, int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int accumulate,
+                                  int dtype, pdmk_stream s) {
+    if (!ws || !C || M <= 0 || N <= 0 || (N & 3) || (rowvec && rows_per_b <= 0) || nslab < 1) return -1;
     if (ldrv <= 0) ldrv = N;
     dim3 grid(grid_for(M * (N / 4)));
     if (dtype == PDMK_BF16)
         hipLaunchKernelGGL(splitk_finish_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, ws, (bf16*)C, bias, rowvec,
-                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, accumulate);
+                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate);
     else if (dtype == PDMK_F32)
         hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
-                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, accumulate);
+                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate);
     else return -2;
     PDMK_CHECK_LAUNCH();
     return 0;

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
     const int kt1 = min(nk_total, kt0 + per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     constexpr int ESZ = sizeof(T), G4 = TC::G4;
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
@@ -294,13 +294,15 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
     // global traffic is row-contiguous: 16-byte stores / residual loads per lane on the plain path, and 256 contiguous
     // bytes per wave-instruction on the split-K float-atomic path (scattered 4-byte atomics run ~10x slower).
     const bool first = blockIdx.y == 0;
-    const bool atomic = gridDim.y > 1;
+    const bool slab = g.accumulate == 2;                 // split-K partials to slab blockIdx.y of a [splitk][M][ldc] workspace
+    const bool atomic = gridDim.y > 1 && !slab;
+    const bool acc1 = g.accumulate == 1;
     const bool f32out = g.out_f32 || sizeof(T) == 4;
     const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
     constexpr int SROW = 132;
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(64 * SROW * 4 <= PDMK_GEMM_NBUF * 2 * OPERAND_BYTES, "staging image must fit the tile buffers");
-    float* Cf = reinterpret_cast<float*>(g.C);
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
     T* Ct = reinterpret_cast<T*>(g.C);
     const T* Rp = reinterpret_cast<const T*>(g.R);
 #pragma unroll
@@ -375,14 +377,14 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
                         }
                         if (f32out) {
                             float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                            if (g.accumulate) {
+                            if (acc1) {
                                 const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
                                 o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
                             }
                             *reinterpret_cast<float4*>(Cf + off) = o0;
                             *reinterpret_cast<float4*>(Cf + off + 4) = o1;
                         } else {
-                            if (g.accumulate) {
+                            if (acc1) {
                                 const bf16x8 c = *reinterpret_cast<const bf16x8*>(Ct + off);
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] += (float)c[r];
@@ -399,8 +401,8 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
                             if (g.bias) x += g.bias[n + r];
                             if (rv) x += rv[n + r];
                             if (Rp) x += to_f32(Rp[(long)m * g.ldr + n + r]);
-                            if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
-                            else Ct[off + r] = from_f32<T>(x + (g.accumulate ? to_f32(Ct[off + r]) : 0.f));
+                            if (f32out) Cf[off + r] = x + (acc1 ? Cf[off + r] : 0.f);
+                            else Ct[off + r] = from_f32<T>(x + (acc1 ? to_f32(Ct[off + r]) : 0.f));
                         }
                     }
                 }
@@ -620,11 +622,11 @@ bool ensure_scratch(size_t bytes) {
 float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws, void* fin_out, hipEvent_t e0, hipEvent_t e1) {
     const int reps = 3;
     auto once = [&]() -> int {
-        if (a.splitk > 1 && a.a_mode != PDMK_A_COLK) {
-            if (hipMemsetAsync(ws, 0, (size_t)a.M * a.N * 4, st) != hipSuccess) return -1;
+        if (a.splitk > 1 && a.a_mode != PDMK_A_COLK) {    // slab split-K + the finish pass that adds the slabs
             const int rc = launch_candidate(a, st, id);
             if (rc) return rc;
-            return pdmk_splitk_finish(ws, fin_out, nullptr, nullptr, nullptr, a.M, a.N, a.N, 0, 1, 0, 0, a.dtype, st);
+            return pdmk_splitk_finish(ws, fin_out, nullptr, nullptr, nullptr, a.M, a.N, a.N, 0, 1, 0, a.splitk, 0, a.dtype,
+                                      st);
         }
         return launch_candidate(a, st, id);
     };
@@ -646,20 +648,20 @@ float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws,
 // best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().
 int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     const size_t out_bytes = (size_t)g.M * g.N * 4;
-    if (!ensure_scratch(2 * out_bytes + (size_t)g.M * 4 + 256)) return -1;
+    if (!ensure_scratch((size_t)(sk > 1 ? sk : 1) * out_bytes + out_bytes + (size_t)g.M * 4 + 256)) return -1;
     (void)hipDeviceSynchronize();                    // other streams (teacher branch) must not overlap the timings
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
     pdmk_gemm_args a = g;
-    float* ws = reinterpret_cast<float*>(g_scratch);
-    void* out2 = reinterpret_cast<char*>(g_scratch) + out_bytes;
+    float* ws = reinterpret_cast<float*>(g_scratch);                               // [sk][M][N] slabs (or the output)
+    void* out2 = reinterpret_cast<char*>(g_scratch) + (size_t)(sk > 1 ? sk : 1) * out_bytes;
     a.accumulate = 0;
     a.splitk = sk;
     a.ldc = g.N;
-    if (g.a_mode == PDMK_A_COLK) {           // wgrad: fp32 output, atomics for sk > 1, bias gradient into scratch
-        a.C = ws;
-        if (a.colsum_out) a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(g_scratch) + 2 * out_bytes);
-    } else if (sk > 1) { a.C = ws; a.out_f32 = 1; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
+    if (a.colsum_out)
+        a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(out2) + out_bytes);      // bias gradient -> scratch
+    if (g.a_mode == PDMK_A_COLK) a.C = ws;                                      // wgrad: fp32, atomics for sk > 1
+    else if (sk > 1) { a.C = ws; a.out_f32 = 1; a.accumulate = 2; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
     else a.C = out2;
     int best = -1;
     float bt = 1e30f;
@@ -729,6 +731,8 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
         if (g.conv_ho != eh || g.conv_wo != ew) return -1;
     }
     if (g.splitk > 1 && !(g.out_f32 || g.dtype == PDMK_F32)) return -1;
+    if (g.accumulate == 2 && (g.splitk <= 1 || !(g.out_f32 || g.dtype == PDMK_F32) || g.bias || g.rowvec || g.R)) return -1;
+    if (g.accumulate < 0 || g.accumulate > 2) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_last_candidate = 0;

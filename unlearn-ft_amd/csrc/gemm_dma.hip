@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
     const int kt1 = min(nk_total, kt0 + per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
@@ -184,14 +184,16 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
     // ---------------------------------------------------------------- epilogue (same contract as gemm.hip)
     PDMK_STAMP(2);
     const bool first = blockIdx.y == 0;
-    const bool atomic = gridDim.y > 1;
+    const bool slab = g.accumulate == 2;                 // split-K partials to slab blockIdx.y of a [splitk][M][ldc] workspace
+    const bool atomic = gridDim.y > 1 && !slab;
+    const bool acc1 = g.accumulate == 1;
     const bool f32out = g.out_f32 != 0;
     const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
     constexpr int SROW = 132;
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(64 * SROW * 4 <= STAGES * SLOT_BYTES, "staging image must fit the ring");
     static_assert(2 * NDMA <= 4 || NDMA == 3, "wait_vmcnt instantiations");
-    float* Cf = reinterpret_cast<float*>(g.C);
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
     bf16* Ct = reinterpret_cast<bf16*>(g.C);
     const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
 #pragma unroll
@@ -259,14 +261,14 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
                         }
                         if (f32out) {
                             float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                            if (g.accumulate) {
+                            if (acc1) {
                                 const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
                                 o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
                             }
                             *reinterpret_cast<float4*>(Cf + off) = o0;
                             *reinterpret_cast<float4*>(Cf + off + 4) = o1;
                         } else {
-                            if (g.accumulate) {
+                            if (acc1) {
                                 const bf16x8 c = *reinterpret_cast<const bf16x8*>(Ct + off);
 #pragma unroll
                                 for (int r = 0; r < 8; ++r) v[r] += (float)c[r];
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
                             if (g.bias) x += g.bias[n + r];
                             if (rv) x += rv[n + r];
                             if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
-                            if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
-                            else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
+                            if (f32out) Cf[off + r] = x + (acc1 ? Cf[off + r] : 0.f);
+                            else Ct[off + r] = (bf16)(x + (acc1 ? (float)Ct[off + r] : 0.f));
                         }
                     }
                 }

@@ -59,7 +59,9 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const bool first = blockIdx.y == 0;
-    const bool atomic = gridDim.y > 1;
+    const bool slab = g.accumulate == 2;                 // split-K partials to slab blockIdx.y of a [splitk][M][ldc] workspace
+    const bool atomic = gridDim.y > 1 && !slab;
+    const bool acc1 = g.accumulate == 1;
     const bool f32out = g.out_f32 != 0;
     const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
     constexpr int SROW = BN + 4;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
     constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(64 * SROW * 4 <= LDS_BYTES, "staging image must fit the ring");
-    float* Cf = reinterpret_cast<float*>(g.C);
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
     bf16* Ct = reinterpret_cast<bf16*>(g.C);
     const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
 #pragma unroll
@@ -115,7 +117,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                 const bool ok = item < 64 * C8 && m < g.M && n < g.N;
                 const long off = (long)m * g.ldc + n;
                 if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
-                if (ok && g.accumulate && !f32out) cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
+                if (ok && acc1 && !f32out) cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
             }
             __syncthreads();
 #pragma unroll
@@ -145,7 +147,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                 const long off = (long)m * g.ldc + n;
                 if (f32out) {
                     float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-                    if (g.accumulate) {       // fp32 accumulate (weight gradients without split-K): read in place
+                    if (acc1) {       // fp32 accumulate (weight gradients without split-K): read in place
                         const float4 c0 = *reinterpret_cast<const float4*>(Cf + off), c1 = *reinterpret_cast<const float4*>(Cf + off + 4);
                         o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w;
                         o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
@@ -153,7 +155,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                     *reinterpret_cast<float4*>(Cf + off) = o0;
                     *reinterpret_cast<float4*>(Cf + off + 4) = o1;
                 } else {
-                    if (g.accumulate) {
+                    if (acc1) {
 #pragma unroll
                         for (int r = 0; r < 8; ++r) v[r] += (float)cprev[it][r];
                     }
@@ -177,8 +179,8 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                     if (g.bias) x += g.bias[n + r];
                     if (rv) x += rv[n + r];
                     if (Rp) x += (float)Rp[(long)m * g.ldr + n + r];
-                    if (f32out) Cf[off + r] = x + (g.accumulate ? Cf[off + r] : 0.f);
-                    else Ct[off + r] = (bf16)(x + (g.accumulate ? (float)Ct[off + r] : 0.f));
+                    if (f32out) Cf[off + r] = x + (acc1 ? Cf[off + r] : 0.f);
+                    else Ct[off + r] = (bf16)(x + (acc1 ? (float)Ct[off + r] : 0.f));
                 }
             }
         }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
     const int kt1 = min(nk_total, kt0 + per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const int ncb_total = (Ci + 63) / 64;
     const int per = (ncb_total + gridDim.y - 1) / gridDim.y;
     const int cb0 = blockIdx.y * per, cb1 = min(ncb_total, cb0 + per);
-    if (cb0 >= cb1) return;
+    if (cb0 >= cb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     // tile geometry: R rows of one image (HW >= BM) or BM/HW whole images
     const int rimg = HW >= BM ? BM / W : H;                           // rows of an image inside the tile
@@ -431,10 +433,10 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const unsigned b_row = (unsigned)(wn * (16 * NJ) + fr) * 128u;
 
     // ---- prologue: the first patch, then BSTAGES-1 weight tiles
-    const int nsteps = (cb1 - cb0) * 9;
+    const int nsteps = cb1 > cb0 ? (cb1 - cb0) * 9 : 0;
 #pragma unroll
     for (int j = 0; j < NPW; ++j)
-        if ((j * 8 + wave) * 8 < prows) issue_piece(cb0, poff[j], j);
+        if (nsteps > 0 && (j * 8 + wave) * 8 < prows) issue_piece(cb0, poff[j], j);
 #pragma unroll
     for (int s = 0; s < BSTAGES - 1; ++s)
         if (s < nsteps) issue_b(cb0 + s / 9, s % 9, s);
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
     const int kt1 = min(nk_total, kt0 + per);
-    if (kt0 >= kt1) return;
+    if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);

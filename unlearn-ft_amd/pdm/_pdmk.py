@@ -48,7 +48,7 @@ _SIGS = {
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
     "pdmk_gemm_last_candidate": ([], i32),
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
-    "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
@@ -116,6 +116,7 @@ PROFILE = None   # bench.py sets this to a list: every gemm launch is then brack
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
          macs=None, colsum_out=None, ldrv=0):
+    # accumulate: False / True / 2 (= split-K slabs, see pdmk.h)
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
     g.colsum_out = _p(colsum_out)
@@ -203,10 +204,27 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
     if sk == 1:
         return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
                     a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs, ldrv=ldrv)
-    ws = zeros((M, N), A.device, torch.float32)
-    gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, macs=macs)
-    _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv,
+    # split-K: every split stores its fp32 partial into its own slab (plain stores: no atomics, no zero-fill, the sum
+    # order is fixed), the finish pass adds the slabs and applies the epilogue
+    ws = torch.empty((sk, M, N), device=A.device, dtype=torch.float32)
+    gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, accumulate=2, macs=macs)
+    splitk_finish(ws, Cout, M, N, ldc, sk, bias=bias, rowvec=rowvec, R=R, ldr=ldr, rows_per_b=rows_per_b, ldrv=ldrv,
+                  accumulate=accumulate)
+
+
+def splitk_finish(ws, Cout, M, N, ldc, nslab, *, bias=None, rowvec=None, R=None, ldr=0, rows_per_b=0, ldrv=0,
+                  accumulate=False):
+    _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv, nslab,
                                  int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")
+
+
+def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=None, macs=None):
+    """dW[M, N] (fp32, row stride N) += dy[K, M]^T x[K, N] (3x3 gather of x for b_mode = B_COLK_CONV), split over the
+    pixel dimension K as the planner says.  Splits add into dW with fp32 atomics: measured against slabs + a finish pass
+    (which is what the forward / dgrad split-K uses) the extra launch per weight cost more than the atomics (-4 %)."""
+    sk = wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode, conv)
+    gemm(dy, x, dW, M, N, K, lda, ldb, N, a_mode=A_COLK, b_mode=b_mode, conv=conv, out_f32=True, splitk=sk,
+         accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
 
 
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps, silu):

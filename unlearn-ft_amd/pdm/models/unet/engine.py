@@ -143,12 +143,9 @@ class UNetEngine:
                     k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
                     dy = dyc
                 xt = x.t
-                sk = k.wgrad_plan(dy, xt, Np, Kp, M, _ld(dy), _ld(xt))
-                # wgrad first (side stream), dgrad second (main stream): the two GEMMs of one layer run side by side
-                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), Kp,
-                                           a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
-                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
-                                           colsum_out=P.g(bias) if bias else None),   # bias gradient fused in
+                # wgrad first (side stream if enabled), dgrad second: the two GEMMs of one layer can run side by side
+                self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), macs=lmacs,
+                                            colsum_out=P.g(bias) if bias else None),   # bias gradient fused in
                             dy, xt)
                 if x.rg:
                     dx, acc = self._grad_into(x, M, Kp)
@@ -186,12 +183,9 @@ class UNetEngine:
                 dy = out.g
                 ldy = _ld(dy)
                 xt = x.t
-                sk = k.wgrad_plan(dy, xt, Cop, 9 * Cip, M, ldy, 0, k.B_COLK_CONV, (B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)))
-                self._wgrad(lambda: k.gemm(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, 9 * Cip,
-                                           a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
-                                           conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), out_f32=True, splitk=sk,
-                                           accumulate=(sk == 1), dtype=k.dt(xt), macs=lmacs,
-                                           colsum_out=None if rowvec is not None else P.g(bias)),
+                self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, b_mode=k.B_COLK_CONV,
+                                            conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), macs=lmacs,
+                                            colsum_out=None if rowvec is not None else P.g(bias)),
                             dy, xt)
                 if x.rg:
                     if mode == 2:

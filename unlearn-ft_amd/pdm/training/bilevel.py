@@ -8,6 +8,7 @@ Reference arithmetic:
   optimisers   trainer.py:265-284, 2695-2717      (torch.optim.AdamW semantics), LR trainer.py:436-443, 2666-2674
   DDP          trainer.py:117-129, 2782, 2808     (gradient mean over ranks)
 """
+import gc
 import math
 
 import os
@@ -411,14 +412,24 @@ class GraphedBilevel:
                     fork_adamw(off)
 
         st.segment_cb = seg_cb if nseg > 1 else None
-        with torch.cuda.stream(cap_stream):
-            graphs[0].capture_begin(capture_error_mode="thread_local")
-            fn()
-            if self.stream_opt and not multi:
-                fork_adamw(0)
-                torch.cuda.current_stream().wait_stream(self.opt_stream)
-                store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
-            graphs[-1].capture_end()
+        # like torch.cuda.graph(): collect garbage first, and keep the collector off while capturing - destroying an old
+        # CUDAGraph (or freeing its pool) from a GC pass in the middle of a capture aborts the process
+        gc.collect()
+        torch.cuda.synchronize()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.stream(cap_stream):
+                graphs[0].capture_begin(capture_error_mode="thread_local")
+                fn()
+                if self.stream_opt and not multi:
+                    fork_adamw(0)
+                    torch.cuda.current_stream().wait_stream(self.opt_stream)
+                    store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
+                graphs[-1].capture_end()
+        finally:
+            if gc_was_on:
+                gc.enable()
         offs.append(0)
         st.segment_cb = None
         torch.cuda.current_stream().wait_stream(cap_stream)
