@@ -449,7 +449,7 @@ def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
         close(y, ref.permute(0, 2, 3, 1).reshape(-1, Co), 2e-2, f"conv mode {mode}")
 
 
-@pytest.mark.parametrize("cand", [0, 1, 2])
+@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5])
 def test_ring_wgrad_candidates(dev, force_cfg, cand):
     from pdm import _pdmk as k
     force_cfg("PDMK_WGRAD_CFG", cand)

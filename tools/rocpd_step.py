@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Per-kernel time inside ONE steady-state main step of a rocprofv3 trace of bench.py (steps are delimited by the AdamW
-launches).  usage: tools/rocpd_step.py <results.db> [step_index] [top_n]"""
+"""Per-kernel time inside ONE steady-state main step of a rocprofv3 trace of bench.py (steps are delimited by the
+forward-diffusion kernel that opens each one).  usage: tools/rocpd_step.py <results.db> [step_index] [top_n]"""
 import re, sqlite3, sys, collections
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select start, end, name, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
-ad = [i for i, r in enumerate(rows) if "adamw" in r[2]]
+ad = [i for i, r in enumerate(rows) if "noise_kernel" in r[2]]   # first kernel of every step
 si = int(sys.argv[2]) if len(sys.argv) > 2 else len(ad) // 2
-seg = rows[ad[si] + 1: ad[si + 1] + 1]
+seg = rows[ad[si]: ad[si + 1]]
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I", n)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the weight-gradient GEMM candidates (0 = register-staged K-step-64 kernel, 1 = 4-slot LDS-DMA ring, 2 = 2-slot
-ring) over split-K factors on the hot wgrad shapes; graph-replayed launches."""
+"""A/B of the weight-gradient GEMM candidates (0 = register-staged K-step-64 kernel, 1/2 = 128x128 deep/shallow LDS-DMA
+ring, 3 = 64x128, 4 = 128x64, 5 = 64x64) over split-K factors on the hot wgrad shapes; graph-replayed launches."""
 import os, sys
 os.environ["PDMK_ENV_DYNAMIC"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ shapes = [lin(32768, 320, 320), lin(32768, 2560, 320), lin(32768, 320, 1280), li
 sks = [1, 2, 4, 8, 16, 32, 64]
 for name, fl, fn in shapes:
     print(name)
-    for cand in (0, 1, 2):
+    for cand in (0, 1, 2, 3, 4, 5):
         os.environ["PDMK_WGRAD_CFG"] = str(cand)
         row = []
         for sk in sks:

@@ -495,13 +495,17 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
 // column of each DMA lane and to the transposing reads: the 8 k-rows one 32-lane read group touches land in 8 different
 // 32-byte bank groups.  The bias gradient (column sums of dY) is one extra MFMA per A fragment against a ones vector, in
 // the workgroups of the first n-tile only.
-template <bool CONV, int STAGES, int OCC>
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
 __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
                                                              unsigned b_bytes) {
     typedef Mma<bf16> MM;
-    constexpr int BM = 128, NJ = 4, BN = 128, IM = 2;
-    constexpr int T_BYTES = 64 * 256, SLOT = 2 * T_BYTES;       // A tile + B tile, 16 KiB each
+    constexpr int BN = 32 * NJ, IM = BM / 64;
+    constexpr int RA = BM * 2, RB = BN * 2;                     // row bytes of the [64 k][BM] / [64 k][BN] tiles: 128 or 256
+    constexpr int A_BYTES = 64 * RA, B_BYTES = 64 * RB, SLOT = A_BYTES + B_BYTES;
+    constexpr int PA = A_BYTES / 1024 / 8, PB = B_BYTES / 1024 / 8;   // DMA pieces per wave and stage (1 KiB each)
+    static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
     static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
+    static_assert(64 * (BN + 4) * 4 <= STAGES * SLOT, "epilogue staging");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -519,11 +523,16 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
     const ConvGeom cg{g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_ld, g.conv_mode};
 
-    // ---- loader: piece (i*8 + wave) of a tile = k-rows 4*(i*8+wave) .. +3; lane -> (row lane>>4, physical chunk lane&15)
-    const int kr_l = lane >> 4;                                      // k-row inside the piece
-    const int fsw = kr_l | (((wave >> 1) & 1) << 2);                 // f(k) of every row this lane loads
-    const int lcn = (lane & 15) ^ (fsw << 1);                        // logical 16-byte chunk = 8 columns
-    const int acol = m0 + lcn * 8, bcol = n0 + lcn * 8;
+    // ---- loaders.  256-byte rows: a piece = 4 k-rows, lane -> (row lane>>4, chunk lane&15), swizzle 2*((k&3) | ((k>>3)&1)<<2).
+    //               128-byte rows: a piece = 8 k-rows, lane -> (row lane>>3, chunk lane&7),  swizzle 2*(((k>>1)&1) | ((k>>3)&1)<<1).
+    // Piece index = i*8 + wave, so the swizzle of every row a lane loads is the same (depends on lane and wave only).
+    auto lane_row = [&](int rbytes) { return rbytes == 256 ? (lane >> 4) : (lane >> 3); };
+    auto lane_lc = [&](int rbytes) {
+        if (rbytes == 256) return (lane & 15) ^ (((lane >> 4) | (((wave >> 1) & 1) << 2)) << 1);
+        return (lane & 7) ^ (((((lane >> 3) >> 1) & 1) | ((wave & 1) << 1)) << 1);
+    };
+    const int a_row = lane_row(RA), b_rowl = lane_row(RB);
+    const int acol = m0 + lane_lc(RA) * 8, bcol = n0 + lane_lc(RB) * 8;
     const bool a_ok = acol < g.M, b_ok = bcol < g.N;
     int b_tap = 0, b_ci = 0;
     if (CONV) {
@@ -534,12 +543,17 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     auto issue = [&](int kt, int slot) {
         unsigned char* sa = smem + slot * SLOT;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PA; ++i) {
             const int piece = i * 8 + wave;
-            const int kr = kt * BK + piece * 4 + kr_l;               // pixel row
-            const bool kok = kr < g.K;
-            const unsigned va = (kok && a_ok) ? ((unsigned)kr * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
+            const int kr = kt * BK + piece * (1024 / RA) + a_row;    // pixel row
+            const unsigned va = (kr < g.K && a_ok) ? ((unsigned)kr * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + piece * 1024), 16, (int)va, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int piece = i * 8 + wave;
+            const int kr = kt * BK + piece * (1024 / RB) + b_rowl;
+            const bool kok = kr < g.K;
             unsigned vb = OOB;
             if (CONV) {
                 if (kok && b_ok) {
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
             } else if (kok && b_ok) {
                 vb = ((unsigned)kr * (unsigned)g.ldb + (unsigned)bcol) * 2u;
             }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + T_BYTES + piece * 1024), 16, (int)vb, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + A_BYTES + piece * 1024), 16, (int)vb, 0, 0, 0);
         }
     };
 
@@ -579,16 +593,15 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
     // transposing fragment reads: lane (g = lane>>4, q = (lane&15)>>2, p = lane&3) reads 8 bytes of k-row kk + 8g + q (and of
-    // row + 4) at columns col0 + 4p; physical chunk = ((col0>>3) ^ 2 f) | (p>>1), f = q | (g&1)<<2
+    // row + 4) at columns col0 + 4p; physical chunk = ((col0>>3) ^ 2 f(k)) | (p>>1)
     const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-    const unsigned t_row = (unsigned)(8 * tg + tq) * 256u + (unsigned)(tp & 1) * 8u;
-    const int t_f2 = (tq | ((tg & 1) << 2)) << 1;
+    const int f256 = (tq | ((tg & 1) << 2)) << 1, f128 = (((tq >> 1) & 1) | ((tg & 1) << 1)) << 1;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    auto tr_frag = [&](const unsigned char* base, int kk, int col0) -> bf16x8 {
-        const unsigned ch = (unsigned)(((col0 >> 3) ^ t_f2) | (tp >> 1));
-        const unsigned char* a0 = base + (unsigned)kk * 256u + t_row + ch * 16u;
+    auto tr_frag = [&](const unsigned char* base, int rbytes, int kk, int col0) -> bf16x8 {
+        const unsigned ch = (unsigned)(((col0 >> 3) ^ (rbytes == 256 ? f256 : f128)) | (tp >> 1));
+        const unsigned char* a0 = base + (unsigned)(kk + 8 * tg + tq) * (unsigned)rbytes + ch * 16u + (unsigned)(tp & 1) * 8u;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 256));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * rbytes));
         s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         return __builtin_bit_cast(bf16x8, v);
     };
@@ -600,18 +613,18 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     int slot = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
         const int ahead = min(STAGES - 2, kt1 - 1 - kt);
-        wait_vmcnt_dyn(ahead * 4);
+        wait_vmcnt_dyn(ahead * (PA + PB));
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, slot == 0 ? STAGES - 1 : slot - 1);
         const unsigned char* sa = smem + slot * SLOT;
-        const unsigned char* sb = sa + T_BYTES;
+        const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 32) {
             bf16x8 af[IM], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < IM; ++i) af[i] = tr_frag(sa, kk, wm * 32 + i * 16);
+            for (int i = 0; i < IM; ++i) af[i] = tr_frag(sa, RA, kk, wm * (16 * IM) + i * 16);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bf[j] = tr_frag(sb, kk, wn * 64 + j * 16);
+            for (int j = 0; j < NJ; ++j) bf[j] = tr_frag(sb, RB, kk, wn * (16 * NJ) + j * 16);
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -626,7 +639,7 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     if (do_colsum && (lane >> 4) == 0) {
 #pragma unroll
         for (int i = 0; i < IM; ++i) {
-            const int m = m0 + wm * 32 + i * 16 + (lane & 15);
+            const int m = m0 + wm * (16 * IM) + i * 16 + (lane & 15);
             if (m < g.M) unsafeAtomicAdd(g.colsum_out + m, acs[i][0]);
         }
     }
@@ -709,11 +722,6 @@ int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demang
     snprintf(buf, n, "pdmk_ring::igemm_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
     return 0;
 }
-int pdmk_wgrad_ring_name(int id, int conv, char* buf, int n) {
-    if (id < 0 || id > 1) return -1;
-    snprintf(buf, n, "pdmk_ring::wgrad_ring_kernel<%s, %d, %d>", conv ? "true" : "false", id == 0 ? 4 : 2, id == 0 ? 2 : 4);
-    return 0;
-}
 int pdmk_gemm_ring_pick(const pdmk_gemm_args& g) { return pdmk_ring::pick_config(g, g.splitk); }
 
 // called by pdmk_gemm (gemm.hip) after argument validation; returns 1 if the shape/config is not handled here
@@ -745,14 +753,25 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-// ---- weight-gradient ring: id 0 = 4-slot ring (one workgroup per CU), id 1 = 2-slot ring (two per CU)
-int pdmk_wgrad_ring_num_configs() { return 2; }
+// ---- weight-gradient ring candidates: 128x128 deep / shallow rings, and the smaller tiles whose split-K epilogue moves a
+// quarter to a half of the atomic bytes per workgroup (what bounds the small weights: ~5 GB/s of atomics per CU)
+struct WCfg { int bm, nj, stages, occ; };
+static const WCfg kWCfgs[] = {{128, 4, 4, 2}, {128, 4, 2, 4}, {64, 4, 3, 4}, {128, 2, 3, 4}, {64, 2, 4, 4}};
+constexpr int kNumW = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
+int pdmk_wgrad_ring_num_configs() { return kNumW; }
+int pdmk_wgrad_ring_name(int id, int conv, char* buf, int n) {
+    if (id < 0 || id >= kNumW) return -1;
+    const WCfg c = kWCfgs[id];
+    snprintf(buf, n, "pdmk_ring::wgrad_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
+    return 0;
+}
 int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
     using namespace pdmk_ring;
     if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
     const bool conv = g.b_mode == PDMK_B_COLK_CONV;
     if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
     if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode > 2)) return 1;
+    if (id < 0 || id >= kNumW) return 1;
     int lg_wo = -1, lg_howo = -1;
     if (conv) {
         auto lg = [](int v) { int l = 0; if (v <= 0 || (v & (v - 1))) return -1; while ((1 << l) < v) ++l; return l; };
@@ -760,13 +779,20 @@ int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes
         lg_howo = lg(g.conv_ho * g.conv_wo);
         if (lg_wo < 0 || lg_howo < 0) lg_wo = lg_howo = -1;
     }
-    dim3 grid(((g.M + 127) / 128) * ((g.N + 127) / 128), g.splitk > 1 ? g.splitk : 1);
-#define PDMK_WG_GO(CV, STv, OCv)                                                                                      \
-    hipLaunchKernelGGL((wgrad_ring_kernel<CV, STv, OCv>), grid, dim3(NT), 0, st, g, lg_wo, lg_howo, (unsigned)a_bytes, \
-                       (unsigned)b_bytes)
-    if (id == 0) { if (conv) PDMK_WG_GO(true, 4, 2); else PDMK_WG_GO(false, 4, 2); }
-    else if (id == 1) { if (conv) PDMK_WG_GO(true, 2, 4); else PDMK_WG_GO(false, 2, 4); }
-    else return 1;
+    const WCfg c = kWCfgs[id];
+    const int bn = 32 * c.nj;
+    dim3 grid(((g.M + c.bm - 1) / c.bm) * ((g.N + bn - 1) / bn), g.splitk > 1 ? g.splitk : 1);
+#define PDMK_WG_GO(BMv, NJv, STv, OCv)                                                                                \
+    case (BMv * 1000 + NJv * 100 + STv * 10 + OCv):                                                                   \
+        if (conv) hipLaunchKernelGGL((wgrad_ring_kernel<true, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, g, lg_wo,  \
+                                     lg_howo, (unsigned)a_bytes, (unsigned)b_bytes);                                  \
+        else hipLaunchKernelGGL((wgrad_ring_kernel<false, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, g, lg_wo,      \
+                                lg_howo, (unsigned)a_bytes, (unsigned)b_bytes);                                       \
+        break;
+    switch (c.bm * 1000 + c.nj * 100 + c.stages * 10 + c.occ) {
+        PDMK_WG_GO(128, 4, 4, 2) PDMK_WG_GO(128, 4, 2, 4) PDMK_WG_GO(64, 4, 3, 4) PDMK_WG_GO(128, 2, 3, 4) PDMK_WG_GO(64, 2, 4, 4)
+        default: return 1;
+    }
 #undef PDMK_WG_GO
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
