@@ -132,11 +132,15 @@ int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gam
 int pdmk_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk,
                   int64_t q_bs, int q_ld, int64_t k_bs, int k_ld, int64_t v_bs, int v_ld, int64_t o_bs, int o_ld,
                   float scale, int dtype, pdmk_stream stream);
-/* delta: [B,H,Nq] float scratch.  dq/dk/dv written (not accumulated) with the same addressing as q/k/v. */
+/* delta: [B,H,Nq] float scratch.  dq/dk/dv written (not accumulated) with the same addressing as q/k/v.
+ * ws (optional, ws_elems floats): with few keys (cross-attention over 77 text tokens) the dK/dV pass also splits the query
+ * sweep over S workgroups per key block and adds their fp32 partials from ws; S <= ws_elems / (2*B*H*Nk*64), S <= 32.
+ * NULL = one workgroup per (key block, head, image). */
 int pdmk_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, int64_t q_bs, int q_ld,
                   int64_t k_bs, int k_ld, int64_t v_bs, int v_ld, int64_t o_bs, int o_ld, int64_t dq_bs, int dq_ld,
-                  int64_t dk_bs, int dk_ld, int64_t dv_bs, int dv_ld, float scale, int dtype, pdmk_stream stream);
+                  int64_t dk_bs, int dk_ld, int64_t dv_bs, int dv_ld, float scale, float* ws, int64_t ws_elems,
+                  int dtype, pdmk_stream stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise / reduction family.

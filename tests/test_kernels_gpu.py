@@ -209,7 +209,7 @@ def test_layernorm(dev, dn, C, M):
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
-@pytest.mark.parametrize("Nq,Nk,H", [(100, 100, 3), (64, 77, 2), (4, 4, 1), (256, 13, 5)])
+@pytest.mark.parametrize("Nq,Nk,H", [(100, 100, 3), (64, 77, 2), (4, 4, 1), (256, 13, 5), (1024, 77, 2), (4096, 13, 1)])
 def test_attention(dev, dn, Nq, Nk, H):
     from pdm import _pdmk as k
     torch.manual_seed(7)

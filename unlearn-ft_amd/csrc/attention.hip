@@ -223,7 +223,10 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
 }
 
 // one workgroup = 64 keys of one (b,h); wave w owns keys 16w..16w+15 (on the lanes); sweeps query blocks of QB rows.
-template <typename T>
+// SPLIT (cross-attention: 77 keys = 2 key blocks, a 32-workgroup grid otherwise): blockIdx.x = split * key_blocks + key
+// block, the workgroup sweeps only its share of the queries and stores fp32 partial dK / dV into slab `split` of `ws`
+// ([nsplit][2][B][H][Nk][64]); attn_dkv_reduce_kernel adds the slabs.
+template <typename T, bool SPLIT>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse,
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
                                                           T* __restrict__ dv, int H, int Nq, int Nk, long q_bs,
                                                           int q_ld, long k_bs, int k_ld, long v_bs, int v_ld,
                                                           long o_bs, int o_ld, long dk_bs, int dk_ld, long dv_bs,
-                                                          int dv_ld, float scale, float scale2) {
+                                                          int dv_ld, float scale, float scale2, float* __restrict__ ws,
+                                                          int nsplit) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
     constexpr int RS = AC::RS, QB = AC::KVB, NQT = QB / 16;
@@ -244,7 +248,15 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     __shared__ float Ls[2][QB], Ds[2][QB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int kblocks = (Nk + 63) / 64;
+    const int split = SPLIT ? blockIdx.x / kblocks : 0;
+    const int k0 = (SPLIT ? blockIdx.x - split * kblocks : blockIdx.x) * 64, h = blockIdx.y, b = blockIdx.z;
+    int q_begin = 0, q_end = Nq;
+    if (SPLIT) {
+        const int nqb = (Nq + QB - 1) / QB, per = (nqb + nsplit - 1) / nsplit;
+        q_begin = min(Nq, split * per * QB);
+        q_end = min(Nq, (split + 1) * per * QB);
+    }
     const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
     const auto ro = make_rsrc(d_o + b * o_bs + h * D, Nq, o_ld);
     const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
@@ -256,9 +268,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     float rl = INFINITY, rd = 0.f;
     KIO::load(rk_, rk, k_ld, k0, Nk, tid);
     KIO::load(rv_, rv, v_ld, k0, Nk, tid);
-    QIO::load(rq_, rq, q_ld, 0, Nq, tid);
-    QIO::load(ro_, ro, o_ld, 0, Nq, tid);
-    if (tid < QB && tid < Nq) { rl = lse_bh[tid]; rd = del_bh[tid]; }
+    QIO::load(rq_, rq, q_ld, q_begin, Nq, tid);
+    QIO::load(ro_, ro, o_ld, q_begin, Nq, tid);
+    if (tid < QB && q_begin + tid < Nq) { rl = lse_bh[q_begin + tid]; rd = del_bh[q_begin + tid]; }
     KIO::store(Ks, rk_, tid);
     KIO::store(Vs, rv_, tid);
     QIO::store(Qs[0], rq_, tid);
@@ -277,8 +289,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     const bool kvalid = k0 + wave * 16 + (lane & 15) < Nk;
 
     int cur = 0;
-    for (int qb = 0; qb < Nq; qb += QB) {
-        const bool more = qb + QB < Nq;
+    for (int qb = q_begin; qb < q_end; qb += QB) {
+        const bool more = qb + QB < q_end;
         if (more) {
             QIO::load(rq_, rq, q_ld, qb + QB, Nq, tid);
             QIO::load(ro_, ro, o_ld, qb + QB, Nq, tid);
@@ -322,6 +334,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if (SPLIT) {       // fp32 partials straight from the accumulators: lane = (d-group g, key), 4 consecutive d per store
+        const int key = k0 + wave * 16 + (lane & 15);
+        if (key < Nk) {
+            const long slab = ((((long)split * 2) * gridDim.z + b) * H + h) * Nk + key;      // dK slab row
+            const long dv_off = (long)gridDim.z * H * Nk;                                     // dV slabs follow dK's
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 a = dkt[dt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] *= scale;
+                *reinterpret_cast<f32x4*>(ws + slab * 64 + dt * 16 + (lane >> 4) * 4) = a;
+                *reinterpret_cast<f32x4*>(ws + (slab + dv_off) * 64 + dt * 16 + (lane >> 4) * 4) = dvt[dt];
+            }
+        }
+        return;
     }
     T* Kw = Ks + wave * 16 * RS;           // K/V staging is free (fragments hoisted, all reads behind barriers)
     T* Vw = Vs + wave * 16 * RS;
@@ -427,6 +455,28 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
     store_tile16<T>(Qw, dq + b * dq_bs + h * D, dq_ld, q0 + wave * 16, Nq, lane);
 }
 
+// dk / dv[b][key][h*64 + d] = sum over the query splits of the fp32 slabs written by attn_bwd_dkv_kernel<T, true>
+template <typename T>
+__global__ void attn_dkv_reduce_kernel(const float* __restrict__ ws, T* __restrict__ dk, T* __restrict__ dv, int B, int H,
+                                       int Nk, int nsplit, long dk_bs, int dk_ld, long dv_bs, int dv_ld) {
+    const long total = (long)2 * B * H * Nk * 16;                    // float4 items of one slab
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    float4 a = *reinterpret_cast<const float4*>(ws + i * 4);
+    for (int s = 1; s < nsplit; ++s) {
+        const float4 u = *reinterpret_cast<const float4*>(ws + ((long)s * total + i) * 4);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    const int d4 = (int)(i & 15);
+    long r = i >> 4;
+    const int key = (int)(r % Nk); r /= Nk;
+    const int h = (int)(r % H); r /= H;
+    const int b = (int)(r % B);
+    const bool is_v = r / B != 0;
+    T* o = (is_v ? dv + b * dv_bs + (long)key * dv_ld : dk + b * dk_bs + (long)key * dk_ld) + h * D + d4 * 4;
+    o[0] = from_f32<T>(a.x); o[1] = from_f32<T>(a.y); o[2] = from_f32<T>(a.z); o[3] = from_f32<T>(a.w);
+}
+
 template <typename T> bool aligned_ok(const void* p, long bs, int ld, long nrows) {
     constexpr int CH = ACfg<T>::CH;
     return (((uintptr_t)p) & 15) == 0 && (bs % CH) == 0 && (ld % CH) == 0 &&
@@ -450,7 +500,7 @@ template <typename T>
 int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
              float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq, int Nk, long q_bs, int q_ld, long k_bs,
              int k_ld, long v_bs, int v_ld, long o_bs, int o_ld, long dq_bs, int dq_ld, long dk_bs, int dk_ld,
-             long dv_bs, int dv_ld, float scale, hipStream_t st) {
+             long dv_bs, int dv_ld, float scale, float* ws, long ws_elems, hipStream_t st) {
     if (!aligned_ok<T>(q, q_bs, q_ld, Nq) || !aligned_ok<T>(k, k_bs, k_ld, Nk) || !aligned_ok<T>(v, v_bs, v_ld, Nk) ||
         !aligned_ok<T>(o, o_bs, o_ld, Nq) || !aligned_ok<T>(d_o, o_bs, o_ld, Nq) || !aligned_ok<T>(dq, dq_bs, dq_ld, Nq) ||
         !aligned_ok<T>(dk, dk_bs, dk_ld, Nk) || !aligned_ok<T>(dv, dv_bs, dv_ld, Nk))
@@ -458,9 +508,26 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
     const long total = (long)B * H * Nq;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((int)min(4096L, (total + NT - 1) / NT)), dim3(NT), 0, st,
                        (const T*)o, (const T*)d_o, delta, H, Nq, o_bs, o_ld, total);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<T>, dim3((Nk + 63) / 64, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs,
-                       v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E);
+    // few keys (cross-attention): also split the query sweep, or the grid is only key_blocks*H*B workgroups
+    const int kblocks = (Nk + 63) / 64, qblocks = (Nq + ACfg<T>::KVB - 1) / ACfg<T>::KVB;
+    int nsplit = 1;
+    if (ws && kblocks * H * B < 128 && qblocks >= 8) {
+        nsplit = min(min(32, qblocks / 4), (256 + kblocks * H * B - 1) / (kblocks * H * B));
+        const long per = (long)2 * B * H * Nk * 64;
+        if (nsplit > ws_elems / per) nsplit = (int)(ws_elems / per);
+    }
+    if (nsplit > 1) {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true>), dim3(kblocks * nsplit, H, B), dim3(NT), 0, st, (const T*)q,
+                           (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, k_bs,
+                           k_ld, v_bs, v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E, ws, nsplit);
+        const long items = (long)2 * B * H * Nk * 16;
+        hipLaunchKernelGGL(attn_dkv_reduce_kernel<T>, dim3((unsigned)((items + NT - 1) / NT)), dim3(NT), 0, st, ws, (T*)dk,
+                           (T*)dv, B, H, Nk, nsplit, dk_bs, dk_ld, dv_bs, dv_ld);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false>), dim3(kblocks, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs,
+                           v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E, nullptr, 1);
+    }
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld,
                        o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E);
@@ -486,15 +553,16 @@ extern "C" int pdmk_attn_bwd(const void* q, const void* k, const void* v, const 
                              const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int Nq,
                              int Nk, int64_t q_bs, int q_ld, int64_t k_bs, int k_ld, int64_t v_bs, int v_ld,
                              int64_t o_bs, int o_ld, int64_t dq_bs, int dq_ld, int64_t dk_bs, int dk_ld,
-                             int64_t dv_bs, int dv_ld, float scale, int dtype, pdmk_stream stream) {
+                             int64_t dv_bs, int dv_ld, float scale, float* ws, int64_t ws_elems, int dtype,
+                             pdmk_stream stream) {
     if (!q || !k || !v || !o || !d_o || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0)
         return -1;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PDMK_BF16)
         return attn_bwd<bf16>(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld,
-                              o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, st);
+                              o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, ws, (long)ws_elems, st);
     if (dtype == PDMK_F32)
         return attn_bwd<float>(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs,
-                               v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, st);
+                               v_ld, o_bs, o_ld, dq_bs, dq_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, ws, (long)ws_elems, st);
     return -2;
 }

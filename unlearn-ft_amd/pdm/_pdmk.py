@@ -55,7 +55,7 @@ _SIGS = {
     "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
     "pdmk_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
-                       i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
+                       i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, vp, i64, i32, vp], i32),
     "pdmk_geglu_fwd": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_geglu_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_silu_fwd": ([vp, vp, i64, i32, vp], i32),
@@ -270,9 +270,13 @@ def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale):
 
 
 def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_, dqs, dks, dvs, scale):
+    ws = None
+    if Nk <= 128 and Nq >= 512:          # cross-attention: few keys -> the dK/dV pass also splits the queries (pdmk.h)
+        ws = torch.empty(2 * 16 * B * H * Nk * 64, device=q.device, dtype=torch.float32)
     _chk(_lib.pdmk_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Nq,
                             Nk, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], dqs[0], dqs[1], dks[0],
-                            dks[1], dvs[0], dvs[1], scale, dt(q), _st()), "pdmk_attn_bwd")
+                            dks[1], dvs[0], dvs[1], scale, _p(ws), 0 if ws is None else ws.numel(), dt(q), _st()),
+         "pdmk_attn_bwd")
 
 
 def geglu_fwd(x, y, M, Fd, ldx, ldy):
