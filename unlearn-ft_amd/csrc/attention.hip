@@ -14,6 +14,8 @@
 //   dQ      : S^T = K Q^T                                  dQ^T += K^T dS^T
 // K/V (resp. Q/dO) tiles are double buffered in LDS; the next tile's buffer loads (hardware zero-fill past the sequence
 // end) are issued before the current tile's MFMAs: one barrier per tile.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -26,10 +28,46 @@ constexpr unsigned OOB = 0x80000000u;
 
 template <typename T> struct ACfg;
 template <> struct ACfg<bf16> {
-    static constexpr int CH = 8, RS = 72, KVB = 64;   // RS: LDS row stride of a [rows][64] tile; KVB: streamed rows
+    static constexpr int CH = 8, RS = 64, KVB = 64;   // RS: LDS row stride of a [rows][64] tile; KVB: streamed rows
 };
 template <> struct ACfg<float> {
     static constexpr int CH = 4, RS = 68, KVB = 32;
+};
+
+// LDS tile addressing.  bf16: unpadded 128-byte rows with the 16-byte chunk index XOR-ed with (row & 7): conflict-free both
+// for the row-wise ds_read_b128 fragments (Q / K / dO rows as MFMA operands) and for the transposing ds_read_b64_tr_b16
+// reads of the same image in accumulator order (8 consecutive rows per 32-lane group) - the padded [rows][72] image it
+// replaces spent 36-43 % of its LDS cycles on bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  fp32: padded.
+template <typename T> struct AT;
+template <> struct AT<bf16> {
+    typedef Mma<bf16> MM;
+    static constexpr int RS = 64;
+    static __device__ __forceinline__ int sw(int row) { return row & 7; }
+    static __device__ __forceinline__ MM::frag rowk(const bf16* lds, int row0, int k0, int lane) {
+        const int row = row0 + (lane & 15), ch = ((k0 >> 3) + (lane >> 4)) ^ (row & 7);
+        return *reinterpret_cast<const bf16x8*>(lds + row * RS + ch * 8);
+    }
+    template <int S> static __device__ __forceinline__ MM::frag colk_accs(const bf16* lds, int k0, int col0, int lane) {
+        const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int row = k0 + 4 * g + q;                        // rows row and row + 16 share (row & 7)
+        const bf16* a0 = lds + row * RS + ((((col0 >> 3) + (p >> 1)) ^ (row & 7)) * 8) + (p & 1) * 4;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 16 * RS));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    }
+};
+template <> struct AT<float> {
+    typedef Mma<float> MM;
+    static constexpr int RS = 68;
+    static __device__ __forceinline__ int sw(int) { return 0; }
+    static __device__ __forceinline__ MM::frag rowk(const float* lds, int row0, int k0, int lane) {
+        return MM::load_rowk(lds, RS, row0, k0, lane);
+    }
+    template <int S> static __device__ __forceinline__ MM::frag colk_accs(const float* lds, int k0, int col0, int lane) {
+        return MM::template load_colk_accs<S>(lds, RS, k0, col0, lane);
+    }
 };
 
 // A [ROWS][64] tile of a strided [N][..] matrix: buffer loads into registers (rows past the end read as zero), LDS
@@ -49,8 +87,8 @@ template <typename T, int ROWS> struct TileIO {
     static __device__ __forceinline__ void store(T* lds, const u32x4* r, int tid) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int c = tid + i * NT;
-            *reinterpret_cast<u32x4*>(lds + (c / CPR) * RS + (c % CPR) * CH) = r[i];
+            const int c = tid + i * NT, row = c / CPR;
+            *reinterpret_cast<u32x4*>(lds + row * RS + (((c % CPR) ^ AT<T>::sw(row)) * CH)) = r[i];
         }
     }
 };
@@ -93,7 +131,10 @@ template <typename MM, int NS> struct AccLoop<MM, NS, NS> {
 };
 
 // ================================================================================================ forward
-template <typename T>
+// one workgroup = 64*NQ queries of one (b,h); wave w owns NQ tiles of 16 queries (on the lanes) and sweeps the keys in
+// tiles of KVB.  NQ = 2 halves the K / V fragment reads per MFMA (every fragment feeds both query tiles): the loop is
+// LDS-read bound at NQ = 1 (24 reads per 16 MFMAs).
+template <typename T, int NQ>
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, T* __restrict__ o,
                                                       float* __restrict__ lse, int H, int Nq, int Nk, long q_bs,
@@ -101,35 +142,52 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
                                                       int o_ld, float scale2) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16;
-    typedef TileIO<T, 64> QIO;
+    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16, QROWS = 64 * NQ;
+    typedef TileIO<T, QROWS> QIO;
     typedef TileIO<T, KVB> KIO;
-    __shared__ __attribute__((aligned(16))) T Qs[64 * RS];
+    __shared__ __attribute__((aligned(16))) T Qs[QROWS * RS];
     __shared__ __attribute__((aligned(16))) T Ks[2][KVB * RS];
     __shared__ __attribute__((aligned(16))) T Vs[2][KVB * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QROWS, h = blockIdx.y, b = blockIdx.z;
     const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
     const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
     const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
 
-    u32x4 rq_[QIO::NR], rk_[KIO::NR], rv_[KIO::NR];
-    QIO::load(rq_, rq, q_ld, q0, Nq, tid);
-    KIO::load(rk_, rk, k_ld, 0, Nk, tid);
-    KIO::load(rv_, rv, v_ld, 0, Nk, tid);
-    QIO::store(Qs, rq_, tid);
+    u32x4 rk_[KIO::NR], rv_[KIO::NR];
+    {
+        u32x4 rq_[QIO::NR];
+        QIO::load(rq_, rq, q_ld, q0, Nq, tid);
+        KIO::load(rk_, rk, k_ld, 0, Nk, tid);
+        KIO::load(rv_, rv, v_ld, 0, Nk, tid);
+        QIO::store(Qs, rq_, tid);
+    }
     KIO::store(Ks[0], rk_, tid);
     KIO::store(Vs[0], rv_, tid);
     __syncthreads();
-    typename MM::frag qf[D / MM::KS];      // B operand: B[k = d][col = query]
+    typename MM::frag qf[NQ][D / MM::KS];  // B operand: B[k = d][col = query]
 #pragma unroll
-    for (int kk = 0; kk < D / MM::KS; ++kk) qf[kk] = MM::load_rowk(Qs, RS, wave * 16, kk * MM::KS, lane);
+    for (int n = 0; n < NQ; ++n)
+#pragma unroll
+        for (int kk = 0; kk < D / MM::KS; ++kk) qf[n][kk] = AT<T>::rowk(Qs, (wave * NQ + n) * 16, kk * MM::KS, lane);
 
-    f32x4 ot[4];                            // O^T[d = dt*16 + 4g + r][query = lane&15]
+    f32x4 ot[NQ][4], ol[NQ];                // O^T[d = dt*16 + 4g + r][query = lane&15]; ol: softmax denominators
+    float m_run[NQ];                        // running row maximum (scaled scores), per query column
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;   // per query column (l: this lane group's share)
+    for (int n = 0; n < NQ; ++n) {
+        m_run[n] = -INFINITY;
+        ol[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ot[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    typename MM::frag ones;
+    if constexpr (std::is_same<T, bf16>::value) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    } else {
+        ones = 1.0f;
+    }
 
     int cur = 0;
     for (int kb = 0; kb < Nk; kb += KVB) {
@@ -138,46 +196,67 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
             KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
             KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
         }
-        f32x4 st[NKT];                      // S^T[key = 16t + 4g + r][query]
-        float mx = -INFINITY;
+        f32x4 st[NQ][NKT];                  // S^T[key = 16t + 4g + r][query]
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < D / MM::KS; ++kk)
-                st[t] = MM::mma(MM::load_rowk(Ks[cur], RS, t * 16, kk * MM::KS, lane), qf[kk], st[t]);
+            for (int n = 0; n < NQ; ++n) st[n][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool valid = kb + t * 16 + (lane >> 4) * 4 + r < Nk;
-                st[t][r] = valid ? st[t][r] * scale2 : -INFINITY;
-                mx = fmaxf(mx, st[t][r]);
+            for (int kk = 0; kk < D / MM::KS; ++kk) {
+                const typename MM::frag kf = AT<T>::rowk(Ks[cur], t * 16, kk * MM::KS, lane);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) st[n][t] = MM::mma(kf, qf[n][kk], st[n][t]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - mn);
-        m_run = mn;
-        l_run *= alpha;
+        // softmax on the raw scores (the loop is VALU-bound at d = 64: per score element max, fma, exp2 and half a
+        // convert; the scale rides in the fma, the row sum is an MFMA against a ones fragment, masking only in a tail tile)
+        const bool tail = kb + KVB > Nk;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int n = 0; n < NQ; ++n) {
+            float mx = -INFINITY;
+            if (tail) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ot[dt][r] *= alpha;
+                for (int t = 0; t < NKT; ++t)
 #pragma unroll
-        for (int t = 0; t < NKT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[t][r] = exp2f(st[t][r] - mn);
-                l_run += st[t][r];
+                    for (int r = 0; r < 4; ++r)
+                        if (kb + t * 16 + (lane >> 4) * 4 + r >= Nk) st[n][t][r] = -INFINITY;
             }
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[n][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m_run[n], mx * scale2);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[n] - mn);
+            m_run[n] = mn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ol[n][r] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ot[n][dt][r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[n][t][r] = __builtin_amdgcn_exp2f(fmaf(st[n][t][r], scale2, -mn));
+        }
 #pragma unroll
         for (int pr = 0; pr < NKT / 2; ++pr) {
             AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
                 constexpr int S = decltype(sc)::value;
-                const typename MM::frag pf = MM::template acc_frag<S>(st[2 * pr], st[2 * pr + 1]);
+                typename MM::frag pf[NQ];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    ot[dt] = MM::mma(MM::template load_colk_accs<S>(Vs[cur], RS, pr * 32, dt * 16, lane), pf, ot[dt]);
+                for (int n = 0; n < NQ; ++n) {
+                    pf[n] = MM::template acc_frag<S>(st[n][2 * pr], st[n][2 * pr + 1]);
+                    ol[n] = MM::mma(ones, pf[n], ol[n]);             // row sums of P: every row of ol is l
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const typename MM::frag vf = AT<T>::template colk_accs<S>(Vs[cur], pr * 32, dt * 16, lane);
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n) ot[n][dt] = MM::mma(vf, pf[n], ot[n][dt]);
+                }
             });
         }
         if (more) {
@@ -187,14 +266,18 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
         __syncthreads();
         cur ^= 1;
     }
-    l_run += __shfl_xor(l_run, 16, 64);
-    l_run += __shfl_xor(l_run, 32, 64);
-    T* Ow = Qs + wave * 16 * RS;           // this wave's own Q rows, free since qf was hoisted
-    stage_t<T>(Ow, ot, 1.0f / l_run, lane);
-    const int qi = q0 + wave * 16 + (lane & 15);
-    if (lane < 16 && qi < Nq) lse[((long)b * H + h) * Nq + qi] = m_run + log2f(l_run);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float l = ol[n][0];
+        T* Ow = Qs + (wave * NQ + n) * 16 * RS;        // this wave's own Q rows, free since qf was hoisted
+        stage_t<T>(Ow, ot[n], 1.0f / l, lane);
+        const int qi = q0 + (wave * NQ + n) * 16 + (lane & 15);
+        if (lane < 16 && qi < Nq) lse[((long)b * H + h) * Nq + qi] = m_run[n] + log2f(l);
+    }
     __syncthreads();
-    store_tile16<T>(Ow, o + b * o_bs + h * D, o_ld, q0 + wave * 16, Nq, lane);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        store_tile16<T>(Qs + (wave * NQ + n) * 16 * RS, o + b * o_bs + h * D, o_ld, q0 + (wave * NQ + n) * 16, Nq, lane);
 }
 
 // ================================================================================================ backward
@@ -222,11 +305,12 @@ __global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__
     }
 }
 
-// one workgroup = 64 keys of one (b,h); wave w owns keys 16w..16w+15 (on the lanes); sweeps query blocks of QB rows.
-// SPLIT (cross-attention: 77 keys = 2 key blocks, a 32-workgroup grid otherwise): blockIdx.x = split * key_blocks + key
-// block, the workgroup sweeps only its share of the queries and stores fp32 partial dK / dV into slab `split` of `ws`
-// ([nsplit][2][B][H][Nk][64]); attn_dkv_reduce_kernel adds the slabs.
-template <typename T, bool SPLIT>
+// one workgroup = 64*NKW keys of one (b,h); wave w owns NKW tiles of 16 keys (on the lanes); sweeps query blocks of QB
+// rows.  Every Q / dO fragment (row-wise for S and dP, transposed for dV and dK) feeds all NKW key tiles.
+// SPLIT (cross-attention: 77 keys = 2 key blocks, a 32-workgroup grid otherwise; NKW = 1): blockIdx.x = split *
+// key_blocks + key block, the workgroup sweeps only its share of the queries and stores fp32 partial dK / dV into slab
+// `split` of `ws` ([nsplit][2][B][H][Nk][64]); attn_dkv_reduce_kernel adds the slabs.
+template <typename T, bool SPLIT, int NKW>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ v, const T* __restrict__ d_o,
                                                           const float* __restrict__ lse,
@@ -238,19 +322,20 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
                                                           int nsplit) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, QB = AC::KVB, NQT = QB / 16;
-    typedef TileIO<T, 64> KIO;
+    constexpr int RS = AC::RS, QB = AC::KVB, NQT = QB / 16, KROWS = 64 * NKW;
+    typedef TileIO<T, KROWS> KIO;
     typedef TileIO<T, QB> QIO;
-    __shared__ __attribute__((aligned(16))) T Ks[64 * RS];     // K, V staging; reused for the dK / dV output staging
-    __shared__ __attribute__((aligned(16))) T Vs[64 * RS];
+    static_assert(!SPLIT || NKW == 1, "the query split is for few-key grids");
+    __shared__ __attribute__((aligned(16))) T Ks[KROWS * RS];  // K, V staging; reused for the dK / dV output staging
+    __shared__ __attribute__((aligned(16))) T Vs[KROWS * RS];
     __shared__ __attribute__((aligned(16))) T Qs[2][QB * RS];
     __shared__ __attribute__((aligned(16))) T Os[2][QB * RS];
-    __shared__ float Ls[2][QB], Ds[2][QB];
+    __shared__ float Ls[2][QB], Ds[2][QB];                     // -lse, -delta of the query block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kblocks = (Nk + 63) / 64;
+    const int kblocks = (Nk + KROWS - 1) / KROWS;
     const int split = SPLIT ? blockIdx.x / kblocks : 0;
-    const int k0 = (SPLIT ? blockIdx.x - split * kblocks : blockIdx.x) * 64, h = blockIdx.y, b = blockIdx.z;
+    const int k0 = (SPLIT ? blockIdx.x - split * kblocks : blockIdx.x) * KROWS, h = blockIdx.y, b = blockIdx.z;
     int q_begin = 0, q_end = Nq;
     if (SPLIT) {
         const int nqb = (Nq + QB - 1) / QB, per = (nqb + nsplit - 1) / nsplit;
@@ -264,29 +349,37 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     const float* lse_bh = lse + ((long)b * H + h) * Nq;
     const float* del_bh = delta + ((long)b * H + h) * Nq;
 
-    u32x4 rk_[KIO::NR], rv_[KIO::NR], rq_[QIO::NR], ro_[QIO::NR];
-    float rl = INFINITY, rd = 0.f;
-    KIO::load(rk_, rk, k_ld, k0, Nk, tid);
-    KIO::load(rv_, rv, v_ld, k0, Nk, tid);
-    QIO::load(rq_, rq, q_ld, q_begin, Nq, tid);
-    QIO::load(ro_, ro, o_ld, q_begin, Nq, tid);
-    if (tid < QB && q_begin + tid < Nq) { rl = lse_bh[q_begin + tid]; rd = del_bh[q_begin + tid]; }
-    KIO::store(Ks, rk_, tid);
-    KIO::store(Vs, rv_, tid);
+    u32x4 rq_[QIO::NR], ro_[QIO::NR];
+    float rl = -INFINITY, rd = 0.f;
+    {
+        u32x4 rk_[KIO::NR], rv_[KIO::NR];
+        KIO::load(rk_, rk, k_ld, k0, Nk, tid);
+        KIO::load(rv_, rv, v_ld, k0, Nk, tid);
+        QIO::load(rq_, rq, q_ld, q_begin, Nq, tid);
+        QIO::load(ro_, ro, o_ld, q_begin, Nq, tid);
+        if (tid < QB && q_begin + tid < Nq) { rl = -lse_bh[q_begin + tid]; rd = -del_bh[q_begin + tid]; }
+        KIO::store(Ks, rk_, tid);
+        KIO::store(Vs, rv_, tid);
+    }
     QIO::store(Qs[0], rq_, tid);
     QIO::store(Os[0], ro_, tid);
     if (tid < QB) { Ls[0][tid] = rl; Ds[0][tid] = rd; }
     __syncthreads();
-    typename MM::frag kf[D / MM::KS], vf[D / MM::KS];      // B operands: B[k = d][col = key]
+    typename MM::frag kf[NKW][D / MM::KS], vf[NKW][D / MM::KS];  // B operands: B[k = d][col = key]
+    f32x4 dkt[NKW][4], dvt[NKW][4];        // dK^T / dV^T [d = dt*16 + 4g + r][key = lane&15]
+    bool kvalid[NKW];
 #pragma unroll
-    for (int kk = 0; kk < D / MM::KS; ++kk) {
-        kf[kk] = MM::load_rowk(Ks, RS, wave * 16, kk * MM::KS, lane);
-        vf[kk] = MM::load_rowk(Vs, RS, wave * 16, kk * MM::KS, lane);
+    for (int j = 0; j < NKW; ++j) {
+#pragma unroll
+        for (int kk = 0; kk < D / MM::KS; ++kk) {
+            kf[j][kk] = AT<T>::rowk(Ks, (wave * NKW + j) * 16, kk * MM::KS, lane);
+            vf[j][kk] = AT<T>::rowk(Vs, (wave * NKW + j) * 16, kk * MM::KS, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dkt[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        kvalid[j] = k0 + (wave * NKW + j) * 16 + (lane & 15) < Nk;
     }
-    f32x4 dkt[4], dvt[4];                  // dK^T / dV^T [d = dt*16 + 4g + r][key = lane&15]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { dkt[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const bool kvalid = k0 + wave * 16 + (lane & 15) < Nk;
+    const bool ktail = k0 + KROWS > Nk;    // only the last key block masks keys
 
     int cur = 0;
     for (int qb = q_begin; qb < q_end; qb += QB) {
@@ -294,36 +387,59 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
         if (more) {
             QIO::load(rq_, rq, q_ld, qb + QB, Nq, tid);
             QIO::load(ro_, ro, o_ld, qb + QB, Nq, tid);
-            rl = INFINITY; rd = 0.f;
-            if (tid < QB && qb + QB + tid < Nq) { rl = lse_bh[qb + QB + tid]; rd = del_bh[qb + QB + tid]; }
+            rl = -INFINITY; rd = 0.f;
+            if (tid < QB && qb + QB + tid < Nq) { rl = -lse_bh[qb + QB + tid]; rd = -del_bh[qb + QB + tid]; }
         }
-        f32x4 p[NQT], ds[NQT];             // P / dS [query = 16t + 4g + r][key]
+        f32x4 p[NKW][NQT], ds[NKW][NQT];   // P / dS [query = 16t + 4g + r][key]
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 sacc[NKW], dp[NKW];
+            f32x4 nd;                      // dP starts at -delta (dS = P * (dP - delta) without the subtraction)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nd[r] = Ds[cur][t * 16 + (lane >> 4) * 4 + r];
+#pragma unroll
+            for (int j = 0; j < NKW; ++j) { sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = nd; }
 #pragma unroll
             for (int kk = 0; kk < D / MM::KS; ++kk) {
-                s = MM::mma(MM::load_rowk(Qs[cur], RS, t * 16, kk * MM::KS, lane), kf[kk], s);
-                dp = MM::mma(MM::load_rowk(Os[cur], RS, t * 16, kk * MM::KS, lane), vf[kk], dp);
+                const typename MM::frag qa = AT<T>::rowk(Qs[cur], t * 16, kk * MM::KS, lane);
+                const typename MM::frag oa = AT<T>::rowk(Os[cur], t * 16, kk * MM::KS, lane);
+#pragma unroll
+                for (int j = 0; j < NKW; ++j) {
+                    sacc[j] = MM::mma(qa, kf[j][kk], sacc[j]);
+                    dp[j] = MM::mma(oa, vf[j][kk], dp[j]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qq = t * 16 + (lane >> 4) * 4 + r;
-                const float pv = kvalid ? exp2f(s[r] * scale2 - Ls[cur][qq]) : 0.f;
-                p[t][r] = pv;
-                ds[t][r] = pv * (dp[r] - Ds[cur][qq]);
+                const float nl = Ls[cur][t * 16 + (lane >> 4) * 4 + r];
+#pragma unroll
+                for (int j = 0; j < NKW; ++j) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale2, nl));
+                    if (ktail && !kvalid[j]) pv = 0.f;
+                    p[j][t][r] = pv;
+                    ds[j][t][r] = pv * dp[j][r];
+                }
             }
         }
 #pragma unroll
         for (int pr = 0; pr < NQT / 2; ++pr) {
             AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
                 constexpr int S = decltype(sc)::value;
-                const typename MM::frag pf = MM::template acc_frag<S>(p[2 * pr], p[2 * pr + 1]);
-                const typename MM::frag sf = MM::template acc_frag<S>(ds[2 * pr], ds[2 * pr + 1]);
+                typename MM::frag pf[NKW], sf[NKW];
+#pragma unroll
+                for (int j = 0; j < NKW; ++j) {
+                    pf[j] = MM::template acc_frag<S>(p[j][2 * pr], p[j][2 * pr + 1]);
+                    sf[j] = MM::template acc_frag<S>(ds[j][2 * pr], ds[j][2 * pr + 1]);
+                }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
-                    dvt[dt] = MM::mma(MM::template load_colk_accs<S>(Os[cur], RS, pr * 32, dt * 16, lane), pf, dvt[dt]);
-                    dkt[dt] = MM::mma(MM::template load_colk_accs<S>(Qs[cur], RS, pr * 32, dt * 16, lane), sf, dkt[dt]);
+                    const typename MM::frag oc = AT<T>::template colk_accs<S>(Os[cur], pr * 32, dt * 16, lane);
+                    const typename MM::frag qc = AT<T>::template colk_accs<S>(Qs[cur], pr * 32, dt * 16, lane);
+#pragma unroll
+                    for (int j = 0; j < NKW; ++j) {
+                        dvt[j][dt] = MM::mma(oc, pf[j], dvt[j][dt]);
+                        dkt[j][dt] = MM::mma(qc, sf[j], dkt[j][dt]);
+                    }
                 }
             });
         }
@@ -342,26 +458,31 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
             const long dv_off = (long)gridDim.z * H * Nk;                                     // dV slabs follow dK's
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                f32x4 a = dkt[dt];
+                f32x4 a = dkt[0][dt];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] *= scale;
                 *reinterpret_cast<f32x4*>(ws + slab * 64 + dt * 16 + (lane >> 4) * 4) = a;
-                *reinterpret_cast<f32x4*>(ws + (slab + dv_off) * 64 + dt * 16 + (lane >> 4) * 4) = dvt[dt];
+                *reinterpret_cast<f32x4*>(ws + (slab + dv_off) * 64 + dt * 16 + (lane >> 4) * 4) = dvt[0][dt];
             }
         }
         return;
     }
-    T* Kw = Ks + wave * 16 * RS;           // K/V staging is free (fragments hoisted, all reads behind barriers)
-    T* Vw = Vs + wave * 16 * RS;
-    stage_t<T>(Kw, dkt, scale, lane);
-    stage_t<T>(Vw, dvt, 1.0f, lane);
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) {        // K/V staging is free (fragments hoisted, all reads behind barriers)
+        stage_t<T>(Ks + (wave * NKW + j) * 16 * RS, dkt[j], scale, lane);
+        stage_t<T>(Vs + (wave * NKW + j) * 16 * RS, dvt[j], 1.0f, lane);
+    }
     __syncthreads();
-    store_tile16<T>(Kw, dk + b * dk_bs + h * D, dk_ld, k0 + wave * 16, Nk, lane);
-    store_tile16<T>(Vw, dv + b * dv_bs + h * D, dv_ld, k0 + wave * 16, Nk, lane);
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) {
+        store_tile16<T>(Ks + (wave * NKW + j) * 16 * RS, dk + b * dk_bs + h * D, dk_ld, k0 + (wave * NKW + j) * 16, Nk, lane);
+        store_tile16<T>(Vs + (wave * NKW + j) * 16 * RS, dv + b * dv_bs + h * D, dv_ld, k0 + (wave * NKW + j) * 16, Nk, lane);
+    }
 }
 
-// one workgroup = 64 queries of one (b,h); wave w owns 16 queries (on the lanes); sweeps key blocks.
-template <typename T>
+// one workgroup = 64*NQ queries of one (b,h); wave w owns NQ tiles of 16 queries (on the lanes); sweeps key blocks.
+// Every K / V fragment feeds all NQ query tiles (NQ = 2 halves the LDS reads per MFMA).
+template <typename T, int NQ>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                          const T* __restrict__ v, const T* __restrict__ d_o,
                                                          const float* __restrict__ lse,
@@ -371,43 +492,50 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
                                                          int dq_ld, float scale, float scale2) {
     typedef Mma<T> MM;
     typedef ACfg<T> AC;
-    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16;
-    typedef TileIO<T, 64> QIO;
+    constexpr int RS = AC::RS, KVB = AC::KVB, NKT = KVB / 16, QROWS = 64 * NQ;
+    typedef TileIO<T, QROWS> QIO;
     typedef TileIO<T, KVB> KIO;
-    __shared__ __attribute__((aligned(16))) T Qs[64 * RS];      // Q staging, then dQ output staging
-    __shared__ __attribute__((aligned(16))) T Os[64 * RS];
+    __shared__ __attribute__((aligned(16))) T Qs[QROWS * RS];   // Q staging, then dQ output staging
+    __shared__ __attribute__((aligned(16))) T Os[QROWS * RS];
     __shared__ __attribute__((aligned(16))) T Ks[2][KVB * RS];
     __shared__ __attribute__((aligned(16))) T Vs[2][KVB * RS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QROWS, h = blockIdx.y, b = blockIdx.z;
     const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
     const auto ro = make_rsrc(d_o + b * o_bs + h * D, Nq, o_ld);
     const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
     const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
 
-    u32x4 rq_[QIO::NR], ro_[QIO::NR], rk_[KIO::NR], rv_[KIO::NR];
-    QIO::load(rq_, rq, q_ld, q0, Nq, tid);
-    QIO::load(ro_, ro, o_ld, q0, Nq, tid);
-    KIO::load(rk_, rk, k_ld, 0, Nk, tid);
-    KIO::load(rv_, rv, v_ld, 0, Nk, tid);
-    QIO::store(Qs, rq_, tid);
-    QIO::store(Os, ro_, tid);
+    u32x4 rk_[KIO::NR], rv_[KIO::NR];
+    {
+        u32x4 rq_[QIO::NR], ro_[QIO::NR];
+        QIO::load(rq_, rq, q_ld, q0, Nq, tid);
+        QIO::load(ro_, ro, o_ld, q0, Nq, tid);
+        KIO::load(rk_, rk, k_ld, 0, Nk, tid);
+        KIO::load(rv_, rv, v_ld, 0, Nk, tid);
+        QIO::store(Qs, rq_, tid);
+        QIO::store(Os, ro_, tid);
+    }
     KIO::store(Ks[0], rk_, tid);
     KIO::store(Vs[0], rv_, tid);
     __syncthreads();
-    typename MM::frag qf[D / MM::KS], of[D / MM::KS];       // B operands: B[k = d][col = query]
+    typename MM::frag qf[NQ][D / MM::KS], of[NQ][D / MM::KS];       // B operands: B[k = d][col = query]
+    float nl2[NQ], ndl[NQ];                                         // -lse, -delta of this lane's query
+    f32x4 dqt[NQ][4];                                               // dQ^T[d][query]
 #pragma unroll
-    for (int kk = 0; kk < D / MM::KS; ++kk) {
-        qf[kk] = MM::load_rowk(Qs, RS, wave * 16, kk * MM::KS, lane);
-        of[kk] = MM::load_rowk(Os, RS, wave * 16, kk * MM::KS, lane);
+    for (int n = 0; n < NQ; ++n) {
+#pragma unroll
+        for (int kk = 0; kk < D / MM::KS; ++kk) {
+            qf[n][kk] = AT<T>::rowk(Qs, (wave * NQ + n) * 16, kk * MM::KS, lane);
+            of[n][kk] = AT<T>::rowk(Os, (wave * NQ + n) * 16, kk * MM::KS, lane);
+        }
+        const int qi = q0 + (wave * NQ + n) * 16 + (lane & 15);
+        nl2[n] = qi < Nq ? -lse[((long)b * H + h) * Nq + qi] : -INFINITY;
+        ndl[n] = qi < Nq ? -delta[((long)b * H + h) * Nq + qi] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dqt[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int qi = q0 + wave * 16 + (lane & 15);
-    const float l2 = qi < Nq ? lse[((long)b * H + h) * Nq + qi] : INFINITY;
-    const float dl = qi < Nq ? delta[((long)b * H + h) * Nq + qi] : 0.f;
-    f32x4 dqt[4];                           // dQ^T[d][query]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dqt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int cur = 0;
     for (int kb = 0; kb < Nk; kb += KVB) {
@@ -416,30 +544,48 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
             KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
             KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
         }
-        f32x4 dst[NKT];                     // dS^T[key = 16t + 4g + r][query]
+        const bool tail = kb + KVB > Nk;
+        f32x4 dst[NQ][NKT];                 // dS^T[key = 16t + 4g + r][query]
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 s[NQ], dp[NQ];
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {  // dP starts at -delta: dS = P * (dP - delta) needs no subtraction
+                s[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dp[n] = f32x4{ndl[n], ndl[n], ndl[n], ndl[n]};
+            }
 #pragma unroll
             for (int kk = 0; kk < D / MM::KS; ++kk) {
-                s = MM::mma(MM::load_rowk(Ks[cur], RS, t * 16, kk * MM::KS, lane), qf[kk], s);
-                dp = MM::mma(MM::load_rowk(Vs[cur], RS, t * 16, kk * MM::KS, lane), of[kk], dp);
+                const typename MM::frag kf = AT<T>::rowk(Ks[cur], t * 16, kk * MM::KS, lane);
+                const typename MM::frag vf = AT<T>::rowk(Vs[cur], t * 16, kk * MM::KS, lane);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    s[n] = MM::mma(kf, qf[n][kk], s[n]);
+                    dp[n] = MM::mma(vf, of[n][kk], dp[n]);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool valid = kb + t * 16 + (lane >> 4) * 4 + r < Nk;
-                const float pv = valid ? exp2f(s[r] * scale2 - l2) : 0.f;
-                dst[t][r] = pv * (dp[r] - dl);
-            }
+            for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(s[n][r], scale2, nl2[n]));
+                    if (tail && kb + t * 16 + (lane >> 4) * 4 + r >= Nk) pv = 0.f;
+                    dst[n][t][r] = pv * dp[n][r];
+                }
         }
 #pragma unroll
         for (int pr = 0; pr < NKT / 2; ++pr) {
             AccLoop<MM, 0, MM::ACC_STEPS>::run([&](auto sc) {
                 constexpr int S = decltype(sc)::value;
-                const typename MM::frag sf = MM::template acc_frag<S>(dst[2 * pr], dst[2 * pr + 1]);
+                typename MM::frag sf[NQ];
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-                    dqt[dt] = MM::mma(MM::template load_colk_accs<S>(Ks[cur], RS, pr * 32, dt * 16, lane), sf, dqt[dt]);
+                for (int n = 0; n < NQ; ++n) sf[n] = MM::template acc_frag<S>(dst[n][2 * pr], dst[n][2 * pr + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const typename MM::frag kc = AT<T>::template colk_accs<S>(Ks[cur], pr * 32, dt * 16, lane);
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n) dqt[n][dt] = MM::mma(kc, sf[n], dqt[n][dt]);
+                }
             });
         }
         if (more) {
@@ -449,10 +595,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
         __syncthreads();
         cur ^= 1;
     }
-    T* Qw = Qs + wave * 16 * RS;
-    stage_t<T>(Qw, dqt, scale, lane);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) stage_t<T>(Qs + (wave * NQ + n) * 16 * RS, dqt[n], scale, lane);
     __syncthreads();
-    store_tile16<T>(Qw, dq + b * dq_bs + h * D, dq_ld, q0 + wave * 16, Nq, lane);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        store_tile16<T>(Qs + (wave * NQ + n) * 16 * RS, dq + b * dq_bs + h * D, dq_ld, q0 + (wave * NQ + n) * 16, Nq, lane);
 }
 
 // dk / dv[b][key][h*64 + d] = sum over the query splits of the fp32 slabs written by attn_bwd_dkv_kernel<T, true>
@@ -489,9 +637,18 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, i
     if (!aligned_ok<T>(q, q_bs, q_ld, Nq) || !aligned_ok<T>(k, k_bs, k_ld, Nk) || !aligned_ok<T>(v, v_bs, v_ld, Nk) ||
         !aligned_ok<T>(o, o_bs, o_ld, Nq))
         return -1;
-    dim3 grid((Nq + 63) / 64, H, B);
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, grid, dim3(NT), 0, st, (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, H,
-                       Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale * LOG2E);
+    // 32 queries per wave when there are enough query blocks to fill the chip that way, else 16 (PDMK_ATTN_NQ forces)
+    static int forced = -1, dynamic = -1;
+    if (dynamic < 0) dynamic = getenv("PDMK_ENV_DYNAMIC") ? 1 : 0;
+    if (forced < 0 || dynamic) { const char* e = getenv("PDMK_ATTN_NQ"); forced = e ? atoi(e) : 0; }
+    const bool wide = forced ? forced == 2 : ((long)((Nq + 127) / 128) * H * B >= 384 && Nk >= 256);
+    if (wide) {
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)o, lse, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale * LOG2E);
+    } else {
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 1>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)o, lse, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale * LOG2E);
+    }
     PDMK_CHECK_LAUNCH();
     return 0;
 }
@@ -508,6 +665,10 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
     const long total = (long)B * H * Nq;
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((int)min(4096L, (total + NT - 1) / NT)), dim3(NT), 0, st,
                        (const T*)o, (const T*)d_o, delta, H, Nq, o_bs, o_ld, total);
+    // PDMK_ATTN_NQ (with PDMK_ENV_DYNAMIC) forces 16 (1) / 32 (2) rows per wave in all three kernels
+    static int forced = -1, dynamic = -1;
+    if (dynamic < 0) dynamic = getenv("PDMK_ENV_DYNAMIC") ? 1 : 0;
+    if (forced < 0 || dynamic) { const char* e = getenv("PDMK_ATTN_NQ"); forced = e ? atoi(e) : 0; }
     // few keys (cross-attention): also split the query sweep, or the grid is only key_blocks*H*B workgroups
     const int kblocks = (Nk + 63) / 64, qblocks = (Nq + ACfg<T>::KVB - 1) / ACfg<T>::KVB;
     int nsplit = 1;
@@ -516,21 +677,28 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
         const long per = (long)2 * B * H * Nk * 64;
         if (nsplit > ws_elems / per) nsplit = (int)(ws_elems / per);
     }
+#define PDMK_DKV_ARGS (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, \
+                      k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E
     if (nsplit > 1) {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true>), dim3(kblocks * nsplit, H, B), dim3(NT), 0, st, (const T*)q,
-                           (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, k_bs,
-                           k_ld, v_bs, v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E, ws, nsplit);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, true, 1>), dim3(kblocks * nsplit, H, B), dim3(NT), 0, st, PDMK_DKV_ARGS, ws,
+                           nsplit);
         const long items = (long)2 * B * H * Nk * 16;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel<T>, dim3((unsigned)((items + NT - 1) / NT)), dim3(NT), 0, st, ws, (T*)dk,
                            (T*)dv, B, H, Nk, nsplit, dk_bs, dk_ld, dv_bs, dv_ld);
+    } else if (forced == 2) {      // 32 keys per wave: measured slower than 16 (190 VGPRs, 65 KiB LDS) - kept for A/B only
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false, 2>), dim3((Nk + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DKV_ARGS,
+                           nullptr, 1);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false>), dim3(kblocks, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
-                           (const T*)v, (const T*)d_o, lse, delta, (T*)dk, (T*)dv, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs,
-                           v_ld, o_bs, o_ld, dk_bs, dk_ld, dv_bs, dv_ld, scale, scale * LOG2E, nullptr, 1);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false, 1>), dim3(kblocks, H, B), dim3(NT), 0, st, PDMK_DKV_ARGS, nullptr, 1);
     }
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
-                       (const T*)v, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld,
-                       o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E);
+#undef PDMK_DKV_ARGS
+#define PDMK_DQ_ARGS (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, \
+                     v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E
+    if (forced == 2)               // 32 queries per wave: no gain in the backward (unlike the forward) - A/B only
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
+#undef PDMK_DQ_ARGS
     PDMK_CHECK_LAUNCH();
     return 0;
 }
