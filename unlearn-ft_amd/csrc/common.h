@@ -140,7 +140,25 @@ __device__ __forceinline__ float silu_grad_f(float x) {
     const float s = sigmoid_fast(x);
     return s * (1.0f + x * (1.0f - s));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (GEGLU's gate, blocks.py:55) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far inside the fp32
+// parity tolerance) on the hardware exp2 / rcp; erf(x / sqrt 2) and the Gaussian of the derivative share ONE exponential.
+// libm erff + expf are ~50 VALU instructions per element and made the GEGLU kernels VALU-bound.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {       // cdf = Phi(x), e = exp(-x^2 / 2)
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);                    // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f),
+                                0.254829592f);
+    const float erf_abs = 1.0f - poly * e;                                        // erf(|x| / sqrt 2)
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return cdf + x * 0.39894228040143268f * e;
 }
