@@ -202,7 +202,12 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
+    // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
+    // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
+    const int ntm = (g.M + BM - 1) / BM;
+    const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int nk_total = (g.K + BK - 1) / BK;
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
@@ -350,7 +355,12 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
+    // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
+    // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
+    const int ntm = (g.M + BM - 1) / BM;
+    const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int H = g.conv_hi, W = g.conv_wi, Ci = g.conv_ci, HW = H * W;
     const int ncb_total = (Ci + 63) / 64;
     const int per = (ncb_total + gridDim.y - 1) / gridDim.y;
@@ -512,7 +522,12 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
+    // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
+    // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
+    const int ntm = (g.M + BM - 1) / BM;
+    const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int nk_total = (g.K + BK - 1) / BK;
     const int per = (nk_total + gridDim.y - 1) / gridDim.y;
     const int kt0 = blockIdx.y * per;
