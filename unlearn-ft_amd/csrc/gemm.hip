@@ -681,7 +681,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
 
 int heuristic_cfg(const pdmk_gemm_args& g) {
     if (!ring_mode()) return 0;
-    if (g.a_mode == PDMK_A_COLK) return 1;
+    if (g.a_mode == PDMK_A_COLK) return g.b_mode == PDMK_B_COLK_CONV ? 2 : 0;   // what the tuned plans pick most often
     return 1 + pdmk_gemm_ring_pick(g);
 }
 
@@ -694,13 +694,18 @@ int heuristic_wgrad_sk(const pdmk_gemm_args& g) {     // untuned default: ~512 w
     return s < 1 ? 1 : s;
 }
 
-int heuristic_sk(const pdmk_gemm_args& g) {           // untuned default: only deep-K, few-tile GEMMs are split
-    const int tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const int nk = g.K / 64;
-    if (tiles > 160 || nk < 64 || (tiles > 96 && nk < 160) || (g.N & 3)) return 1;
-    const int a = nk / 16, b = (256 + tiles - 1) / tiles;
-    const int s = a < b ? a : b;
-    return s < 1 ? 1 : (s > 16 ? 16 : s);
+int heuristic_sk(const pdmk_gemm_args& g) {           // untuned default: split until ~256 workgroups, >= 8 K-steps each
+    if (g.N & 3) return 1;
+    const bool conv0 = g.a_mode == PDMK_A_CONV && g.conv_mode == 0;
+    const int bm = conv0 ? (g.M >= 8192 ? 256 : 128) : (g.M >= 8192 ? 128 : 64);
+    const int bn = conv0 ? 160 : 128;
+    const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn);
+    const int nk = (g.K + 63) / 64;
+    if (tiles >= 160 || nk < 30) return 1;
+    long s = (256 + tiles - 1) / tiles;
+    if (s > nk / 8) s = nk / 8;
+    if (conv0 && s > (g.conv_ci + 63) / 64) s = (g.conv_ci + 63) / 64;
+    return s < 1 ? 1 : (s > 16 ? 16 : (int)s);
 }
 
 }  // namespace

@@ -671,24 +671,40 @@ static const Config kConfigs[] = {
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
-// Untuned default (graph capture of a shape never seen eagerly, PDMK_GEMM_TUNE=0): fill the 256 CUs in as few, as
-// full rounds as possible; among equals the bigger tile.  cost = rounds x (fixed + K-steps x per-K-step time).
-static int pick_config(const pdmk_gemm_args& g, int splitk) {
-    const double nk = (double)((g.K + BK - 1) / BK) / (splitk > 1 ? splitk : 1);
-    double best = 1e30;
-    int bi = 2;
-    for (int id = 0; id < 6; ++id) {
-        const int bm = kConfigs[id].bm, bn = 32 * kConfigs[id].nj;
-        const long wgs = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * (splitk > 1 ? splitk : 1);
-        const double rounds = (double)((wgs + 255) / 256);
-        const double mfma = (double)bm * bn * BK * 2 / 4096.0 / 0.80;        // cycles at 80 % of 4096 FLOP/clk/CU
-        const double feed = (double)(bm + bn) * 128.0 / 40.0;                // operand stream at ~40 B/clk/CU
-        const double kstep = mfma > feed ? mfma : feed;
-        const double fixed = 4000.0 + 22.0 * bm;                             // prologue + epilogue passes
-        const double cost = rounds * (fixed + nk * kstep);
-        if (cost < best) { best = cost; bi = id; }
+// Halo-conv shapes (candidate ids kNumConfigs + h): tile rows, channel tiles, patch capacity; eligibility of a conv.
+static bool halo_ok(const pdmk_gemm_args& g, int h, int splitk) {
+    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return false;
+    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return false;
+    const int bm = h < 2 ? 256 : 128, pmax = h < 2 ? 400 : 264;
+    const int HW = g.conv_hi * g.conv_wi, W = g.conv_wi;
+    int prows;
+    if (HW >= bm) {
+        if ((HW % bm) || (bm % W)) return false;
+        prows = (bm / W + 2) * (W + 2);
+    } else {
+        if (bm % HW) return false;
+        prows = (bm / HW) * (g.conv_hi + 2) * (W + 2);
     }
-    return bi;
+    return prows <= pmax && (splitk > 1 ? splitk : 1) <= (g.conv_ci + 63) / 64;
+}
+
+// Untuned default (graph capture of a shape never seen eagerly, PDMK_GEMM_TUNE=0): the decision tree the tuned plans of
+// the SD-2.1 step condense to (tools/ring_sweep.py; plan files of bench.py).  Stride-1 convs: the halo kernel, 256-row
+// tiles once there are enough of them; Linear and the strided convs: the two-workgroups-per-CU shallow rings, tile rows
+// by M.  Returns the ring candidate index (halo shapes follow the ring shapes).
+static int pick_config(const pdmk_gemm_args& g, int splitk) {
+    enum { R256x128, R256x160, R128x128, R128x160, R64x128, R64x160, S128x128, S64x128, S64x160, R128x192, R64x192, S128x160 };
+    const bool n160 = (g.N % 160) == 0 || (g.N > 256 && (g.N % 128) != 0);
+    if (g.a_mode == PDMK_A_CONV && g.conv_mode == 0) {
+        const long t256 = (long)((g.M + 255) / 256) * ((g.N + 159) / 160);
+        const int h = (g.M >= 8192 && t256 >= 128) ? (n160 ? 0 : 1) : (n160 ? 2 : 3);
+        if (halo_ok(g, h, splitk)) return kNumConfigs + h;
+        if (halo_ok(g, h | 2, splitk)) return kNumConfigs + (h | 2);
+    }
+    if (g.M >= 8192) return n160 ? S128x160 : S128x128;
+    if (g.M >= 4096) return S64x160;
+    if (g.M >= 2048 && n160 && g.N >= 1280) return S64x160;
+    return S64x128;
 }
 
 }  // namespace pdmk_ring
@@ -696,21 +712,9 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
 constexpr int kNumHalo = 4;      // halo-conv candidates follow the ring shapes in the candidate numbering
 static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
     using namespace pdmk_ring;
-    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 1;
-    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return 1;
-    const int bm = id < 2 ? 256 : 128, nj = (id & 1) ? 4 : 5, pmax = id < 2 ? 400 : 264;
-    const int HW = g.conv_hi * g.conv_wi, W = g.conv_wi;
-    int prows;
-    if (HW >= bm) {
-        if ((HW % bm) || (bm % W)) return 1;
-        prows = (bm / W + 2) * (W + 2);
-    } else {
-        if (bm % HW) return 1;
-        prows = (bm / HW) * (g.conv_hi + 2) * (W + 2);
-    }
-    if (prows > pmax) return 1;
+    if (!halo_ok(g, id, g.splitk)) return 1;
+    const int bm = id < 2 ? 256 : 128, nj = (id & 1) ? 4 : 5;
     const int sk = g.splitk > 1 ? g.splitk : 1;
-    if (sk > (g.conv_ci + 63) / 64) return 1;
     const int bn = 32 * nj;
     dim3 grid(((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn), sk);
     switch (id) {
