@@ -414,7 +414,10 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
 inline int gn_rows_per_blk(int B, int HW, int sweep, int target_blocks, int max_blk) {
     int nb = (target_blocks + B - 1) / B;
     nb = max(1, min(min(nb, max_blk), HW / max(1, sweep)));
-    return (HW + nb - 1) / nb;
+    int rpb = (HW + nb - 1) / nb;
+    // whole sweeps (rows in flight x unroll) per block: a ragged last sweep runs with a fraction of the threads
+    rpb = (rpb + sweep - 1) / sweep * sweep;
+    return rpb;
 }
 
 template <typename T>
