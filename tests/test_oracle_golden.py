@@ -62,3 +62,26 @@ def test_arch_vector_layout_and_param_count():
     lat, t, ehs = torch.randn(1, 4, 8, 8), torch.tensor([3]), torch.randn(1, 5, 64)
     out = unet.unet_forward(psd, tiny, info, lat, t, ehs)
     assert out.shape == lat.shape and torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------- VAE encoder (oracle/validate_vae_against_reference.py)
+VGOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "vae_twin.npz"))
+
+
+def test_vae_encoder_matches_compvis_encoder():
+    from pdm_ref import vae
+    for tag, cfg in (("tiny", vae.VAEConfig.tiny()),
+                     ("mid", vae.VAEConfig(block_out_channels=(32, 64, 128, 128), layers_per_block=2))):
+        sd = vae.init_state_dict(cfg, seed=7)
+        x = torch.from_numpy(VGOLD[f"{tag}_x"])
+        mom = vae.encode_moments(sd, cfg, x)
+        ref = torch.from_numpy(VGOLD[f"{tag}_moments"])
+        assert mom.shape == ref.shape and torch.allclose(mom, ref, atol=2e-5), tag
+        z = vae.sample_latents(ref * 4.0, torch.from_numpy(VGOLD[f"{tag}_eps"]), 1.0)
+        assert torch.allclose(z, torch.from_numpy(VGOLD[f"{tag}_z4"]), atol=1e-6), tag
+
+
+def test_vae_downsample_is_bottom_right_padded_stride2():
+    x, w, b = (torch.from_numpy(VGOLD[k]) for k in ("ds_x", "ds_w", "ds_b"))
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w, b, stride=2)
+    assert torch.allclose(y, torch.from_numpy(VGOLD["ds_y"]), atol=1e-6)
