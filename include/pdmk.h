@@ -43,6 +43,9 @@ int pdmk_version(void);
  *         0: stride 1   iy=oy+ky-1         1: stride 2   iy=2*oy+ky-1
  *         2: nearest-x2 upsample fused: vy=oy+ky-1 in [0,2Hi) -> iy=vy>>1
  *         3: transposed stride 2 (dgrad of mode 1): vy=oy+ky-1 even, iy=vy/2 < Hi
+ *         4: stride 2 with zero padding on the bottom/right only: iy=2*oy+ky < Hi (the VAE encoder's Downsample2D(padding=0):
+ *            F.pad(x,(0,1,0,1)) + conv stride 2, CompVis twin ldm/modules/diffusionmodules/model.py:60-81); forward only,
+ *            Hi and Wi even
  * A loader thread moves 64 contiguous bytes: K (rowk/conv), M and N (colk) and conv_ci must be multiples of 32 (bf16) /
  * 16 (fp32); lda/ldb/conv_ld multiples of 8 / 4; A/B base pointers 16-byte aligned; each operand < 2 GiB.
  * out_f32: C is float regardless of dtype (parameter gradients).  splitk>1: C must be float and pre-zeroed/accumulating
@@ -221,6 +224,22 @@ int pdmk_skinny_wgrad(const void* dy, int dy_dtype, const void* x, float* dw, fl
                       int lddy, int ldx, int lddw, int dtype, pdmk_stream stream);
 /* sum of squares of n floats into out[slot] (double) — gradient-norm clipping (trainer.py:2323-2325). */
 int pdmk_sumsq(const float* x, int64_t n, double* out, int slot, pdmk_stream stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * VAE encode in front of the step: latents = vae.encode(pixel_values).latent_dist.sample() *
+ * scaling_factor (pdm/training/trainer.py:2405-2406).  The encoder's convs / GroupNorms / projections run on the entry
+ * points above (conv_mode 4 = its Downsample2D); these two are the pieces with no U-Net counterpart.
+ * pdmk_softmax_rows: p[r, 0:cols] = softmax(s[r, 0:cols]); s fp32 (row stride lds), p in `dtype` (row stride ldp);
+ *   cols % 4 == 0, cols <= 16384.  The mid-block attention has ONE head of width 512 (AttnBlock, CompVis twin
+ *   ldm/modules/diffusionmodules/model.py:150-204): its scores are materialised per image by pdmk_gemm (out_f32, alpha =
+ *   C^-1/2), normalised here, and contracted with V by a second pdmk_gemm.
+ * pdmk_latent_sample: DiagonalGaussianDistribution.sample() (twin ldm/modules/distributions/distributions.py:24-37) times
+ *   `scale`: moments NHWC [B*HW, ld] in `dtype` (mean = channels 0..C-1, logvar = C..2C-1, clamped to [-30, 20]); eps and
+ *   latents NCHW fp32 [B, C, HW]: latents = (mean + exp(logvar/2) * eps) * scale. */
+int pdmk_softmax_rows(const float* s, void* p, int64_t rows, int cols, int64_t lds, int64_t ldp, int dtype,
+                      pdmk_stream stream);
+int pdmk_latent_sample(const void* moments, int ld, const float* eps, float* latents, int B, int C, int HW, float scale,
+                       int dtype, pdmk_stream stream);
 
 #ifdef __cplusplus
 }

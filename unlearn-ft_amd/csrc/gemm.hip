@@ -60,12 +60,14 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
     const int ky = (tap * 11) >> 5;          // tap / 3 for tap in [0, 9)
     const int kx = tap - 3 * ky;
     int vy, vx;
-    if (CMODE == 1) { vy = 2 * oy + ky - 1; vx = 2 * ox + kx - 1; }
-    else            { vy = oy + ky - 1;     vx = ox + kx - 1; }
-    const int hv = (CMODE >= 2) ? 2 * g.hi : g.hi, wv = (CMODE >= 2) ? 2 * g.wi : g.wi;
+    if (CMODE == 1)      { vy = 2 * oy + ky - 1; vx = 2 * ox + kx - 1; }
+    else if (CMODE == 4) { vy = 2 * oy + ky;     vx = 2 * ox + kx; }       // padding on the bottom / right only
+    else                 { vy = oy + ky - 1;     vx = ox + kx - 1; }
+    constexpr bool UP = CMODE == 2 || CMODE == 3;
+    const int hv = UP ? 2 * g.hi : g.hi, wv = UP ? 2 * g.wi : g.wi;
     bool ok = (unsigned)vy < (unsigned)hv && (unsigned)vx < (unsigned)wv;
     if (CMODE == 3) ok = ok && (((vy | vx) & 1) == 0);
-    const int iy = (CMODE >= 2) ? (vy >> 1) : vy, ix = (CMODE >= 2) ? (vx >> 1) : vx;
+    const int iy = UP ? (vy >> 1) : vy, ix = UP ? (vx >> 1) : vx;
     return ok ? (b * g.hi + iy) * g.wi + ix : -1;
 }
 
@@ -457,7 +459,8 @@ template <typename T> int launch(const pdmk_gemm_args& g, hipStream_t st) {
             case 0: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 0); break;
             case 1: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 1); break;
             case 2: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 2); break;
-            default: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 3); break;
+            case 3: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 3); break;
+            default: PDMK_GO(PDMK_A_CONV, PDMK_B_ROWK, 4); break;
         }
     } else if (g.a_mode == PDMK_A_COLK && g.b_mode == PDMK_B_COLK) PDMK_GO(PDMK_A_COLK, PDMK_B_COLK, 0);
     else if (g.a_mode == PDMK_A_COLK && g.b_mode == PDMK_B_COLK_CONV) {
@@ -724,15 +727,17 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.b_mode == PDMK_B_ROWK && (g.ldb % ch)) return -1;
     if (g.b_mode == PDMK_B_COLK && ((g.ldb % ch) || (g.N % g4))) return -1;
     if (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) {
-        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 3) return -1;
+        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 4) return -1;
+        if (g.conv_mode == 4 && (g.b_mode == PDMK_B_COLK_CONV || (g.conv_hi & 1) || (g.conv_wi & 1))) return -1;   // forward only
         if (g.conv_b <= 0 || g.conv_hi <= 0 || g.conv_wi <= 0 || g.conv_ho <= 0 || g.conv_wo <= 0) return -1;
         const long px = (long)g.conv_b * g.conv_ho * g.conv_wo;
         if (px >= (1L << 30) || (long)g.conv_b * g.conv_hi * g.conv_wi >= (1L << 30)) return -1;   // 32-bit pixel ids
         if (g.a_mode == PDMK_A_CONV && (g.M != px || g.K != 9 * g.conv_ci)) return -1;
         if (g.b_mode == PDMK_B_COLK_CONV && (g.K != px || g.N != 9 * g.conv_ci)) return -1;
         // gather geometry must be consistent with the source extent (out-of-image taps read as zero padding)
-        const int eh = g.conv_mode == 1 ? (g.conv_hi + 1) / 2 : (g.conv_mode >= 2 ? 2 * g.conv_hi : g.conv_hi);
-        const int ew = g.conv_mode == 1 ? (g.conv_wi + 1) / 2 : (g.conv_mode >= 2 ? 2 * g.conv_wi : g.conv_wi);
+        const bool half = g.conv_mode == 1 || g.conv_mode == 4, twice = g.conv_mode == 2 || g.conv_mode == 3;
+        const int eh = half ? (g.conv_hi + 1) / 2 : (twice ? 2 * g.conv_hi : g.conv_hi);
+        const int ew = half ? (g.conv_wi + 1) / 2 : (twice ? 2 * g.conv_wi : g.conv_wi);
         if (g.conv_ho != eh || g.conv_wo != ew) return -1;
     }
     if (g.splitk > 1 && !(g.out_f32 || g.dtype == PDMK_F32)) return -1;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT, 4) void igemm_dma_kernel(pdmk_gemm_args g, unsi
 int pdmk_gemm_dma_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes) {
     using namespace pdmk_dma;
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
-    if (g.K % BK) return 1;
+    if ((g.K % BK) || (g.a_mode == PDMK_A_CONV && g.conv_mode > 3)) return 1;   // mode 4: ring / K-step-32 register kernels only
     const int nt = (g.N + BN - 1) / BN;
     // 256-row tiles when they still give every CU its two workgroups' worth of blocks (the 64x64-latent layers)
     const bool big = (long)((g.M + 255) / 256) * nt * (g.splitk > 1 ? g.splitk : 1) >= 320;

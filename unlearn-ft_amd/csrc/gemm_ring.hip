@@ -28,8 +28,9 @@ struct ConvGeom {
 __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, int ox, int tap) {
     const int ky = (tap * 11) >> 5;
     const int kx = tap - 3 * ky;
-    const bool s2 = g.mode == 1, up = g.mode >= 2;
-    const int vy = (s2 ? 2 * oy : oy) + ky - 1, vx = (s2 ? 2 * ox : ox) + kx - 1;
+    const bool s2 = g.mode == 1 || g.mode == 4, up = g.mode == 2 || g.mode == 3;
+    const int pad = g.mode == 4 ? 0 : 1;                  // mode 4: padding on the bottom / right only
+    const int vy = (s2 ? 2 * oy : oy) + ky - pad, vx = (s2 ? 2 * ox : ox) + kx - pad;
     const int hv = up ? 2 * g.hi : g.hi, wv = up ? 2 * g.wi : g.wi;
     bool ok = (unsigned)vy < (unsigned)hv && (unsigned)vx < (unsigned)wv && tap < 9;
     if (g.mode == 3) ok = ok && (((vy | vx) & 1) == 0);
@@ -789,7 +790,7 @@ int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes
     if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
     const bool conv = g.b_mode == PDMK_B_COLK_CONV;
     if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
-    if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode > 2)) return 1;
+    if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3)) return 1;
     if (id < 0 || id >= kNumW) return 1;
     int lg_wo = -1, lg_howo = -1;
     if (conv) {

@@ -77,6 +77,8 @@ _SIGS = {
     "pdmk_zero": ([vp, i64, vp], i32),
     "pdmk_skinny_gemm": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_skinny_wgrad": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_softmax_rows": ([vp, vp, i64, i32, i64, i64, i32, vp], i32),
+    "pdmk_latent_sample": ([vp, i32, vp, vp, i32, i32, i32, f32, i32, vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
     _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
@@ -333,6 +335,16 @@ def add_noise_velocity(x0, noise, t, sa, sb, noisy, target, B, Cc, HW, cpad):
 
 def nchw_to_nhwc(src, dst, B, Cc, HW, cpad):
     _chk(_lib.pdmk_nchw_to_nhwc(_p(src), _p(dst), B, Cc, HW, cpad, dt(dst), _st()), "pdmk_nchw_to_nhwc")
+
+
+def softmax_rows(s, p, rows, cols, lds, ldp):
+    """p[r, :cols] = softmax(s[r, :cols]) for fp32 scores s; p in the compute dtype."""
+    _chk(_lib.pdmk_softmax_rows(_p(s), _p(p), rows, cols, lds, ldp, dt(p), _st()), "pdmk_softmax_rows")
+
+
+def latent_sample(moments, eps, latents, B, Cc, HW, ld, scale):
+    _chk(_lib.pdmk_latent_sample(_p(moments), ld, _p(eps), _p(latents), B, Cc, HW, float(scale), dt(moments), _st()),
+         "pdmk_latent_sample")
 
 
 def nhwc_to_nchw(src, dst, B, Cc, HW, ld):

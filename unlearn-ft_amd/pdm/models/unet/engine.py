@@ -158,14 +158,15 @@ class UNetEngine:
         return out
 
     def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None):
-        """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather.
+        """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather; 4: stride 2
+        padded on the bottom/right only (VAE encoder downsample; forward only).
         rowvec (+ rv_cols = (first column, width)): per-image row added to every pixel = this ResBlock's column slice of
         the batched time-embedding projection [B, sum of widths] (fp32)."""
         P = self.P
         e = P.by_key[key + ".weight"]
         Cop, _, Cip = e.shape
         assert x.t.shape[1] == Cip, f"{key}: input has {x.t.shape[1]} channels, weight expects {Cip}"
-        Ho, Wo = ((Hi + 1) // 2, (Wi + 1) // 2) if mode == 1 else ((2 * Hi, 2 * Wi) if mode == 2 else (Hi, Wi))
+        Ho, Wo = ((Hi + 1) // 2, (Wi + 1) // 2) if mode in (1, 4) else ((2 * Hi, 2 * Wi) if mode == 2 else (Hi, Wi))
         M = B * Ho * Wo
         y = self._empty(M, Cop)
         k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
