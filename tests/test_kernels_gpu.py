@@ -487,6 +487,37 @@ def test_ring_wgrad_candidates(dev, force_cfg, cand):
 
 
 @pytest.mark.parametrize("cand", [13, 14, 15, 16])
+def test_halo_conv_2d_tiles_on_wide_images(dev, force_cfg, cand):
+    """Images wider than a tile (the VAE encoder's 128^2 .. 512^2 levels): the halo kernel cuts them into rows x tw blocks;
+    output rows of a tile are then not contiguous (2-D row map in the epilogue).  Bias + residual, and split-K slabs."""
+    from pdm import _pdmk as k
+    force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(10)
+    dt = torch.bfloat16
+    for Bn, Hs, Ws, Ci, Co, sk in ((1, 128, 128, 64, 40, 1), (2, 32, 256, 32, 160, 1), (1, 16, 512, 96, 72, 1),
+                                   (1, 64, 128, 160, 64, 2)):
+        x = rnd((Bn, Hs, Ws, Ci), dev, dt)
+        w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
+        bias = torch.randn(Co, device=dev)
+        M = Bn * Hs * Ws
+        R = rnd((M, Co), dev, dt)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+        if sk == 1:
+            y = torch.zeros(M, Co, device=dev, dtype=dt)
+            k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Ws, Ci, Hs, Ws, 0, Ci),
+                   bias=bias, R=R, ldr=Co)
+            ref = ref + bias + R.float()
+        else:
+            ws = torch.full((sk, M, Co), 7.0, device=dev)
+            k.gemm(x, conv_w_pack(w), ws, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Ws, Ci, Hs, Ws, 0, Ci),
+                   out_f32=True, splitk=sk, accumulate=2)
+            y = ws.sum(0)
+        assert k.candidate_name(k.A_CONV, k.B_ROWK, k.last_candidate()).startswith("pdmk_ring::conv_halo_kernel"), \
+            f"{Hs}x{Ws}: halo candidate {cand} was not eligible"
+        close(y, ref, 2e-2, f"halo conv 2-D tiles B{Bn} {Hs}x{Ws} {Ci}->{Co} sk{sk}")
+
+
+@pytest.mark.parametrize("cand", [13, 14, 15, 16])
 def test_halo_conv_candidates(dev, force_cfg, cand):
     """conv_halo_kernel (input patch staged once per 64-channel block, 9 taps out of LDS) vs F.conv2d: row-group tiles,
     whole-image tiles, several images per tile with a missing last image, channel tails, split-K over channel blocks."""

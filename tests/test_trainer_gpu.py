@@ -53,8 +53,25 @@ def test_bilevel_trainer_runs_logs_checkpoints_and_resumes(dev, tmp_path):
     assert all(torch.equal(a[k], b[k]) for k in a)
 
 
-def test_missing_pixels_path_fails_loudly(dev, tmp_path):
+def test_pixel_batches_go_through_the_vae(dev, tmp_path):
+    """The reference's batch schema (`pixel_values`, trainer.py:2405-2406): latents = vae.encode(...).sample() * 0.18215,
+    drawn from the trainer's generator BEFORE the diffusion noise, then the same step as with pre-encoded latents."""
     from pdm.training.trainer import UnetFineTuner
-    tr = UnetFineTuner(_config(tmp_path, 1))
-    with pytest.raises(NotImplementedError):
-        tr.step({"pixel_values": torch.zeros(1, 3, 8, 8), "prompt_embeds": torch.zeros(1, 13, 64)})
+    cfg = _config(tmp_path, 1)
+    cfg["synthetic_pixels"] = True
+    tr = UnetFineTuner(cfg)
+    batch = next(iter(tr.train_dataloader))
+    assert batch["pixel_values"].shape == (2, 3, 64, 64) and "latents" not in batch
+    st = tr.rng.get_state()
+    loss = tr.step(batch)
+    assert all(torch.isfinite(x).all() for x in loss) and loss[0] > 0
+    # the same latents handed over directly reproduce the step's losses (fresh trainer: same weights, same RNG stream)
+    tr2 = UnetFineTuner(cfg)
+    tr2.rng.set_state(st)
+    lat = tr2.vae.encode_latents(batch["pixel_values"], generator=tr2.rng)
+    assert lat.shape == (2, 4, 16, 16)
+    loss2 = tr2.step({"latents": lat, "prompt_embeds": batch["prompt_embeds"]})
+    for a, b in zip(loss, loss2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    with pytest.raises(KeyError):
+        tr.step({"prompt_embeds": batch["prompt_embeds"]})

@@ -53,9 +53,12 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform
 
 // Epilogue shared by the ring kernels (same contract as gemm.hip): accumulators -> LDS staging image (64 rows per pass) ->
 // 16-byte rows of C with bias / rowvec / residual / accumulate fused, or fp32 atomics for split-K launches.
-template <int BM, int NJ, int LDS_BYTES>
+// TILE2D (halo conv on images wider than a tile): the tile is rows x tw output pixels of an image of width img_w, m0 is
+// its first pixel and local row l is pixel m0 + (l / tw) * img_w + l % tw.
+template <int BM, int NJ, int LDS_BYTES, bool TILE2D = false>
 __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&acc)[BM / 64][NJ], unsigned char* smem, int m0,
-                                              int n0) {
+                                              int n0, int tw = 0, int img_w = 0) {
+    auto row_of = [&](int l) { return TILE2D ? m0 + (l / tw) * img_w + (l % tw) : m0 + l; };
     constexpr int BN = 32 * NJ, IM = BM / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -91,7 +94,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
         if (atomic) {
             __syncthreads();
             for (int rr = 0; rr < 8; ++rr) {
-                const int lr2 = wave * 8 + rr, m = m0 + pass * 64 + lr2;
+                const int lr2 = wave * 8 + rr, m = row_of(pass * 64 + lr2);
                 if (m >= g.M) break;
 #pragma unroll
                 for (int h = 0; h < (BN + 63) / 64; ++h) {
@@ -114,7 +117,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = tid + it * NT;
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
                 const bool ok = item < 64 * C8 && m < g.M && n < g.N;
                 const long off = (long)m * g.ldc + n;
                 if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
@@ -125,7 +128,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
             for (int it = 0; it < ITEMS; ++it) {
                 const int item = tid + it * NT;
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
                 if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
                 float v[8];
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
@@ -170,7 +173,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
             __syncthreads();
             for (int item = tid; item < 64 * C8; item += NT) {
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
-                const int m = m0 + pass * 64 + lr2, n = n0 + c8 * 8;
+                const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
                 if (m >= g.M || n >= g.N) continue;
                 const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) : nullptr;
                 const long off = (long)m * g.ldc + n;
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
 // re-issue piece 0 = identical bytes, or read out of bounds = zeros into the finished buffer), so the counted
 // s_waitcnt is a constant.
 template <int BM, int NJ, int BSTAGES, int PMAX>
-__global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+__global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes, int tw) {
     typedef Mma<bf16> MM;
     constexpr int BN = 32 * NJ, IM = BM / 64;
     constexpr int P_BYTES = PMAX * 128, B_BYTES = BN * 128;
@@ -368,12 +371,23 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const int cb0 = blockIdx.y * per, cb1 = min(ncb_total, cb0 + per);
     if (cb0 >= cb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
-    // tile geometry: R rows of one image (HW >= BM) or BM/HW whole images
-    const int rimg = HW >= BM ? BM / W : H;                           // rows of an image inside the tile
-    const int W2 = W + 2, pimg = (rimg + 2) * W2;                     // patch rows per image
+    // tile geometry: rimg rows x tw columns of one image (HW >= BM; tw = W when whole rows fit) or BM/HW whole images
+    const int rimg = HW >= BM ? BM / tw : H;                          // rows of an image inside the tile
+    const int W2 = tw + 2, pimg = (rimg + 2) * W2;                    // patch rows per image
     const int nimg = HW >= BM ? 1 : BM / HW;
     const int prows = nimg * pimg;
-    const int img0 = m0 / HW, y0 = (m0 - img0 * HW) / W;              // first image / first output row of the tile
+    int img0, y0, x0 = 0;                                             // first image / first output row / column of the tile
+    if (tw == W) {
+        img0 = m0 / HW;
+        y0 = (m0 - img0 * HW) / W;
+    } else {
+        const int tpr = W / tw, tpi = (H / rimg) * tpr, tm = m0 / BM;
+        img0 = tm / tpi;
+        const int r = tm - img0 * tpi;
+        y0 = (r / tpr) * rimg;
+        x0 = (r - (r / tpr) * tpr) * tw;
+    }
+    const int mbase = tw == W ? m0 : (img0 * H + y0) * W + x0;        // first output pixel of the tile
 
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
         if (prow < prows) {
             const int il = prow / pimg, rem = prow - il * pimg;
             const int py = rem / W2, px = rem - py * W2;
-            const int b = img0 + il, y = y0 + py - 1, x = px - 1;
+            const int b = img0 + il, y = y0 + py - 1, x = x0 + px - 1;
             if (b < g.conv_b && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
                 poff[j] = (unsigned)((b * H + y) * W + x) * (unsigned)g.conv_ld * 2u;
         }
@@ -435,8 +449,8 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
 #pragma unroll
     for (int i = 0; i < IM; ++i) {
         const int ml = wm * (16 * IM) + i * 16 + fr;                  // output pixel inside the tile
-        const int il = ml / (rimg * W), rem = ml - il * (rimg * W);
-        const int yl = rem / W, x = rem - yl * W;
+        const int il = ml / (rimg * tw), rem = ml - il * (rimg * tw);
+        const int yl = rem / tw, x = rem - yl * tw;
         prow0[i] = il * pimg + yl * W2 + x;
     }
     const int fsw = (fr >> 1) & 7;
@@ -495,7 +509,8 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
             __builtin_amdgcn_sched_barrier(0);        // no cross-tap code motion: keeps fragment live ranges to one tap
         }
     }
-    ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
+    if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
+    else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true>(g, acc, smem, mbase, n0, tw, W);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -673,21 +688,26 @@ static const Config kConfigs[] = {
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 // Halo-conv shapes (candidate ids kNumConfigs + h): tile rows, channel tiles, patch capacity; eligibility of a conv.
-static bool halo_ok(const pdmk_gemm_args& g, int h, int splitk) {
-    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return false;
-    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return false;
+// Tile width for halo shape h on this conv: the image width when whole rows fit the patch buffer, else the widest
+// power-of-two column block (images wider than a tile - the VAE encoder's 128^2..512^2 levels - are cut into
+// rows x tw blocks, e.g. 16 x 16 output pixels + halo = 324 patch rows); 0 = not eligible.
+static int halo_tile_w(const pdmk_gemm_args& g, int h, int splitk) {
+    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 0;
+    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return 0;
+    if ((splitk > 1 ? splitk : 1) > (g.conv_ci + 63) / 64) return 0;
     const int bm = h < 2 ? 256 : 128, pmax = h < 2 ? 400 : 264;
-    const int HW = g.conv_hi * g.conv_wi, W = g.conv_wi;
-    int prows;
-    if (HW >= bm) {
-        if ((HW % bm) || (bm % W)) return false;
-        prows = (bm / W + 2) * (W + 2);
-    } else {
-        if (bm % HW) return false;
-        prows = (bm / HW) * (g.conv_hi + 2) * (W + 2);
+    const int H = g.conv_hi, W = g.conv_wi, HW = H * W;
+    if (HW < bm) return (bm % HW) == 0 && (bm / HW) * (H + 2) * (W + 2) <= pmax ? W : 0;
+    if (HW % bm) return 0;
+    if ((bm % W) == 0 && (bm / W + 2) * (W + 2) <= pmax) return W;
+    for (int tw = 128; tw >= 8; tw >>= 1) {
+        if (tw >= W || (W % tw) || (bm % tw)) continue;
+        const int rows = bm / tw;
+        if ((H % rows) == 0 && (rows + 2) * (tw + 2) <= pmax) return tw;
     }
-    return prows <= pmax && (splitk > 1 ? splitk : 1) <= (g.conv_ci + 63) / 64;
+    return 0;
 }
+static bool halo_ok(const pdmk_gemm_args& g, int h, int splitk) { return halo_tile_w(g, h, splitk) > 0; }
 
 // Untuned default (graph capture of a shape never seen eagerly, PDMK_GEMM_TUNE=0): the decision tree the tuned plans of
 // the SD-2.1 step condense to (tools/ring_sweep.py; plan files of bench.py).  Stride-1 convs: the halo kernel, 256-row
@@ -713,16 +733,17 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
 constexpr int kNumHalo = 4;      // halo-conv candidates follow the ring shapes in the candidate numbering
 static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
     using namespace pdmk_ring;
-    if (!halo_ok(g, id, g.splitk)) return 1;
+    const int tw = halo_tile_w(g, id, g.splitk);
+    if (tw <= 0) return 1;
     const int bm = id < 2 ? 256 : 128, nj = (id & 1) ? 4 : 5;
     const int sk = g.splitk > 1 ? g.splitk : 1;
     const int bn = 32 * nj;
     dim3 grid(((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn), sk);
     switch (id) {
-        case 0: hipLaunchKernelGGL((conv_halo_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
-        case 1: hipLaunchKernelGGL((conv_halo_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
-        case 2: hipLaunchKernelGGL((conv_halo_kernel<128, 5, 4, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
-        case 3: hipLaunchKernelGGL((conv_halo_kernel<128, 4, 5, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes); break;
+        case 0: hipLaunchKernelGGL((conv_halo_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
+        case 1: hipLaunchKernelGGL((conv_halo_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
+        case 2: hipLaunchKernelGGL((conv_halo_kernel<128, 5, 4, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
+        case 3: hipLaunchKernelGGL((conv_halo_kernel<128, 4, 5, 264>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;

@@ -161,6 +161,11 @@ def zero_(t):
     return t
 
 
+def last_candidate():
+    """Candidate id of the calling thread's last pdmk_gemm launch (0 = K-step-32 kernels, 1.. = ring / halo shapes)."""
+    return int(_lib.pdmk_gemm_last_candidate())
+
+
 def candidate_name(a_mode, b_mode, cand):
     buf = C.create_string_buffer(160)
     _chk(_lib.pdmk_gemm_candidate_name(a_mode, b_mode, cand, buf, 160), "pdmk_gemm_candidate_name")

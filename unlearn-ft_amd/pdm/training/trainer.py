@@ -6,7 +6,9 @@ Differences that are deliberate:
    but ALSO run the hand-written backward (there is no autograd graph to hand to accelerator.backward);
  * no accelerate / wandb: ranks come from torch.distributed (RCCL), metrics go to <logging_dir>/metrics.jsonl with the
    reference's key names (trainer.py:2819-2834) and are read back asynchronously (no per-step .item() syncs);
- * batches carry `latents` (VAE encode is SURVEY 8f row N1, not built yet); `--synthetic` produces seeded batches;
+ * batches carry the reference's `pixel_values` (encoded by the frozen VAE on libpdmk, trainer.py:2405-2406) or
+   pre-encoded `latents`; `--synthetic` produces seeded batches of either kind (`synthetic_pixels: true` for pixels);
+   the CLIP text encoder of the dataset transform is SURVEY 8f row N2 (not built): batches carry `prompt_embeds`;
  * torch.autograd.set_detect_anomaly (scripts/aptp/*.py:21) is not reproduced.
 """
 import glob
@@ -36,10 +38,12 @@ def _cfg(config, path, default=None):
 
 
 class SyntheticBatches:
-    """Seeded (latent, prompt-embed) batches of the collate_fn schema (pdm/utils/data_utils.py:286-312) minus pixels."""
+    """Seeded batches of the collate_fn schema (pdm/utils/data_utils.py:286-312): `pixel_values` in [-1, 1] (pixels=True)
+    or pre-encoded `latents`, plus prompt embeddings."""
 
-    def __init__(self, batch_size, hw, ctx_len, ctx_dim, seed, device, length=1 << 30):
+    def __init__(self, batch_size, hw, ctx_len, ctx_dim, seed, device, length=1 << 30, pixels=False, vae_factor=8):
         self.bs, self.hw, self.T, self.D, self.device, self.length = batch_size, hw, ctx_len, ctx_dim, device, length
+        self.pixels, self.res = pixels, hw * vae_factor
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.empty = torch.randn(1, ctx_len, ctx_dim, generator=torch.Generator().manual_seed(1234)).to(device)
 
@@ -48,8 +52,10 @@ class SyntheticBatches:
 
     def __iter__(self):
         for _ in range(self.length):
-            yield {"latents": torch.randn(self.bs, 4, self.hw, self.hw, device=self.device, generator=self.gen),
-                   "prompt_embeds": torch.randn(self.bs, self.T, self.D, device=self.device, generator=self.gen),
+            img = ({"pixel_values": torch.rand(self.bs, 3, self.res, self.res, device=self.device, generator=self.gen) * 2 - 1}
+                   if self.pixels else
+                   {"latents": torch.randn(self.bs, 4, self.hw, self.hw, device=self.device, generator=self.gen)})
+            yield {**img, "prompt_embeds": torch.randn(self.bs, self.T, self.D, device=self.device, generator=self.gen),
                    "empty_prompt_embeds": self.empty.expand(self.bs, -1, -1).contiguous()}
 
 
@@ -73,6 +79,22 @@ class Trainer:
         self.train_dataloader = train_dataloader or self.init_dataloader(upper=False)
         self.upper_dataloader = (upper_dataloader or self.init_dataloader(upper=True)) if self.bilevel else None
         self.rng = torch.Generator(device=self.device).manual_seed(int(_cfg(config, "seed", 43)) + self.rank)
+
+    # ---- frozen VAE (trainer.py:2128-2131, cast to the weight dtype :516-527); built on first use
+    @property
+    def vae_factor(self):
+        return 4 if _cfg(self.config, "tiny", False) else 8
+
+    @property
+    def vae(self):
+        if getattr(self, "_vae", None) is None:
+            from ..models.vae.autoencoder_kl import AutoencoderKL, VAEConfig
+            root = _cfg(self.config, "pretrained_model_name_or_path")
+            local = bool(root) and os.path.isdir(os.path.join(root, "vae"))
+            vcfg = VAEConfig(block_out_channels=(32, 64, 64), layers_per_block=1) if _cfg(self.config, "tiny", False) else None
+            self._vae = AutoencoderKL.from_pretrained(root if local else None, subfolder="vae", random_init=not local,
+                                                      vae_config=vcfg, torch_dtype=self.weight_dtype, device=self.device)
+        return self._vae
 
     # ---- trainer.py:516-527: student master weights fp32; bf16 compute under mixed precision
     def init_weight_dtype(self):
@@ -146,19 +168,23 @@ class Trainer:
         c = self.config
         if not _cfg(c, "synthetic", False):
             raise NotImplementedError(
-                "image datasets + VAE/CLIP encoding are SURVEY 8f rows N1/N2 (not built yet): pass a dataloader "
-                "yielding {'latents','prompt_embeds','empty_prompt_embeds'} or run with --synthetic")
+                "image datasets + CLIP text encoding are SURVEY 8f row N2 (not built yet): pass a dataloader yielding "
+                "{'pixel_values' or 'latents', 'prompt_embeds', 'empty_prompt_embeds'} or run with --synthetic")
         bs = int(_cfg(c, "data.dataloader.train_batch_size", 8))
         res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
         seed = int(_cfg(c, "seed", 43)) + self.rank + (7919 if upper else 0)
         T = 13 if _cfg(c, "tiny", False) else 77
-        return SyntheticBatches(bs, res, T, self.unet_config.cross_attention_dim, seed, self.device)
+        return SyntheticBatches(bs, res, T, self.unet_config.cross_attention_dim, seed, self.device,
+                                pixels=bool(_cfg(c, "synthetic_pixels", False)), vae_factor=self.vae_factor)
 
     # ---- sampling prologue shared by step/upper_step (trainer.py:2405-2423)
     def _sample(self, batch):
-        if "latents" not in batch:
-            raise NotImplementedError("batch has no 'latents': VAE encode of pixel_values is SURVEY 8f row N1")
-        lat = batch["latents"].to(self.device, torch.float32)
+        if "latents" in batch:
+            lat = batch["latents"].to(self.device, torch.float32)
+        elif "pixel_values" in batch:      # trainer.py:2405-2406; the Gaussian draw comes first, as in the reference
+            lat = self.vae.encode_latents(batch["pixel_values"], generator=self.rng)
+        else:
+            raise KeyError("batch has neither 'pixel_values' nor 'latents'")
         noise = torch.randn(lat.shape, device=self.device, generator=self.rng)
         off = float(_cfg(self.config, "model.prediction_model.noise_offset", 0.0) or 0.0)
         if off:
