@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--tiny", action="store_true", help="tiny topology (debug only; result is NOT the benchmark)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--no_roofline", action="store_true")
+    p.add_argument("--no_vae", action="store_true", help="skip the (untimed) VAE-encode extra")
     p.add_argument("--no_graph", action="store_true", help="eager Python launches instead of hipGraph replay")
     return p.parse_args()
 
@@ -186,6 +187,16 @@ def main():
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
+        if world == 1 and not a.no_vae and not a.tiny:
+            # SURVEY 8f N1, NOT part of `value` (SURVEY 8d keeps the VAE off the timed path): what a pixel_values batch adds
+            # in front of every step - vae.encode(pixels).latent_dist.sample() * 0.18215 (trainer.py:2405-2406)
+            from pdm.models.vae.autoencoder_kl import AutoencoderKL
+            vae = AutoencoderKL(None, dev, dtype, seed=0)
+            px = torch.rand(B, 3, a.latent * 8, a.latent * 8, device=dev) * 2 - 1
+            for _ in range(2):
+                vae.encode_latents(px)
+            extras["ms_vae_encode_untimed"] = round(timed(lambda j: vae.encode_latents(px), 3) * 1e3, 2)
+            del vae, px
         n_upper = sum(1 for i in range(a.steps) if (i + 1) % a.upper_freq == 0)
         flop_main = 2.0 * (Tm + 3 * Sm) * B
         flop_upper = 2.0 * (2 * Tm + 3 * Sm) * B

@@ -10,5 +10,7 @@ ModuleNotFoundError, nothing was denied).  The restatement is therefore pinned s
 against the reference pieces that DO import (``oracle/validate_against_reference.py``): compute_snr,
 hard_concrete, gates, and the vendored CompVis ResBlock / SpatialTransformer / Downsample / Upsample /
 timestep_embedding / make_beta_schedule twins; known-answer vectors are committed under tests/golden/.
+``vae.py`` (the VAE encode in front of the step) is pinned the same way against the vendored CompVis
+Encoder / AttnBlock / Downsample / DiagonalGaussianDistribution (``oracle/validate_vae_against_reference.py``).
 """
 from .config import UNetConfig  # noqa: F401

@@ -699,6 +699,10 @@ static int halo_tile_w(const pdmk_gemm_args& g, int h, int splitk) {
     const int H = g.conv_hi, W = g.conv_wi, HW = H * W;
     if (HW < bm) return (bm % HW) == 0 && (bm / HW) * (H + 2) * (W + 2) <= pmax ? W : 0;
     if (HW % bm) return 0;
+    static const int pref = getenv("PDMK_HALO_TW") ? atoi(getenv("PDMK_HALO_TW")) : 0;   // experiment knob: preferred block width
+    if (pref > 0 && pref < W && (W % pref) == 0 && (bm % pref) == 0 && (H % (bm / pref)) == 0 &&
+        (bm / pref + 2) * (pref + 2) <= pmax)
+        return pref;
     if ((bm % W) == 0 && (bm / W + 2) * (W + 2) <= pmax) return W;
     for (int tw = 128; tw >= 8; tw >>= 1) {
         if (tw >= W || (W % tw) || (bm % tw)) continue;
