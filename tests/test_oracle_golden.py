@@ -85,3 +85,23 @@ def test_vae_downsample_is_bottom_right_padded_stride2():
     x, w, b = (torch.from_numpy(VGOLD[k]) for k in ("ds_x", "ds_w", "ds_b"))
     y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w, b, stride=2)
     assert torch.allclose(y, torch.from_numpy(VGOLD["ds_y"]), atol=1e-6)
+
+
+# ---------------------------------------------------------------- CLIP text encoder (oracle/validate_clip_against_transformers.py)
+def test_clip_text_oracle_matches_transformers_outputs():
+    from pdm_ref import clip_text
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text_hf.npz"))
+    for tag, cfg in (("tiny", clip_text.CLIPTextConfig.tiny()),
+                     ("wide", clip_text.CLIPTextConfig(vocab_size=2000, hidden_size=1024, intermediate_size=4096,
+                                                       num_hidden_layers=2, num_attention_heads=16))):
+        sd = clip_text.init_state_dict(cfg, seed=5)
+        out = clip_text.encode(sd, cfg, torch.from_numpy(gold[f"{tag}_ids"]))
+        assert torch.allclose(out, torch.from_numpy(gold[f"{tag}_out"]), atol=2e-5), tag
+    # causality: a token's state does not depend on later tokens
+    cfg = clip_text.CLIPTextConfig.tiny()
+    sd = clip_text.init_state_dict(cfg, seed=5)
+    ids = torch.from_numpy(gold["tiny_ids"])[:1].clone()
+    a = clip_text.encode(sd, cfg, ids)
+    ids[0, 40:] = 7
+    b = clip_text.encode(sd, cfg, ids)
+    assert torch.allclose(a[0, :40], b[0, :40], atol=1e-6) and not torch.allclose(a[0, 40:], b[0, 40:], atol=1e-3)
