@@ -241,6 +241,21 @@ int pdmk_softmax_rows(const float* s, void* p, int64_t rows, int cols, int64_t l
 int pdmk_latent_sample(const void* moments, int ld, const float* eps, float* latents, int B, int C, int HW, float scale,
                        int dtype, pdmk_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Text conditioning: prompt_embeds = text_encoder(input_ids)[0] with transformers.CLIPTextModel
+ * (pdm/utils/data_utils.py:155-191; SD-2.1: 23 pre-LN layers, hidden 1024, 16 heads x 64, erf-GELU MLP, causal mask).
+ * LayerNorm / Linear run on the entry points above; these are the pieces with no U-Net counterpart.
+ * pdmk_embed_tokens: out[i, 0:D] = tok[ids[i], :] + pos[i % T, :] for i < ntok (= B*T); ids int64 on the device, clamped
+ *   to [0, vocab); tables and out in `dtype`, row strides ldt / ldp / ldo.
+ * pdmk_attn_fwd_causal: pdmk_attn_fwd with Nq = Nk = N and key j visible to query i only for j <= i.
+ * pdmk_gelu_fwd: y = x * Phi(x) (exact erf form, hidden_act "gelu") over n contiguous elements. */
+int pdmk_embed_tokens(const int64_t* ids, const void* tok, const void* pos, void* out, int64_t ntok, int T, int D,
+                      int vocab, int ldt, int ldp, int ldo, int dtype, pdmk_stream stream);
+int pdmk_attn_fwd_causal(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N,
+                         int64_t q_bs, int q_ld, int64_t k_bs, int k_ld, int64_t v_bs, int v_ld, int64_t o_bs, int o_ld,
+                         float scale, int dtype, pdmk_stream stream);
+int pdmk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,7 +134,9 @@ template <typename MM, int NS> struct AccLoop<MM, NS, NS> {
 // one workgroup = 64*NQ queries of one (b,h); wave w owns NQ tiles of 16 queries (on the lanes) and sweeps the keys in
 // tiles of KVB.  NQ = 2 halves the K / V fragment reads per MFMA (every fragment feeds both query tiles): the loop is
 // LDS-read bound at NQ = 1 (24 reads per 16 MFMAs).
-template <typename T, int NQ>
+// CAUSAL (CLIP text tower): key j is visible to query i only for j <= i; key 0 is visible to every query, so
+// the first key tile never leaves a row without a finite maximum.
+template <typename T, int NQ, bool CAUSAL = false>
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                       const T* __restrict__ v, T* __restrict__ o,
                                                       float* __restrict__ lse, int H, int Nq, int Nk, long q_bs,
@@ -220,6 +222,14 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (kb + t * 16 + (lane >> 4) * 4 + r >= Nk) st[n][t][r] = -INFINITY;
+            }
+            if (CAUSAL) {
+                const int qi = q0 + (wave * NQ + n) * 16 + (lane & 15);
+#pragma unroll
+                for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb + t * 16 + (lane >> 4) * 4 + r > qi) st[n][t][r] = -INFINITY;
             }
 #pragma unroll
             for (int t = 0; t < NKT; ++t)
@@ -633,10 +643,16 @@ template <typename T> bool aligned_ok(const void* p, long bs, int ld, long nrows
 
 template <typename T>
 int attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Nq, int Nk, long q_bs,
-             int q_ld, long k_bs, int k_ld, long v_bs, int v_ld, long o_bs, int o_ld, float scale, hipStream_t st) {
+             int q_ld, long k_bs, int k_ld, long v_bs, int v_ld, long o_bs, int o_ld, float scale, int causal, hipStream_t st) {
     if (!aligned_ok<T>(q, q_bs, q_ld, Nq) || !aligned_ok<T>(k, k_bs, k_ld, Nk) || !aligned_ok<T>(v, v_bs, v_ld, Nk) ||
         !aligned_ok<T>(o, o_bs, o_ld, Nq))
         return -1;
+    if (causal) {
+        hipLaunchKernelGGL((attn_fwd_kernel<T, 1, true>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, (const T*)q, (const T*)k,
+                           (const T*)v, (T*)o, lse, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale * LOG2E);
+        PDMK_CHECK_LAUNCH();
+        return 0;
+    }
     // 32 queries per wave when there are enough query blocks to fill the chip that way, else 16 (PDMK_ATTN_NQ forces)
     static int forced = -1, dynamic = -1;
     if (dynamic < 0) dynamic = getenv("PDMK_ENV_DYNAMIC") ? 1 : 0;
@@ -711,9 +727,21 @@ extern "C" int pdmk_attn_fwd(const void* q, const void* k, const void* v, void* 
     if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PDMK_BF16)
-        return attn_fwd<bf16>(q, k, v, o, lse, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, st);
+        return attn_fwd<bf16>(q, k, v, o, lse, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, 0, st);
     if (dtype == PDMK_F32)
-        return attn_fwd<float>(q, k, v, o, lse, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, st);
+        return attn_fwd<float>(q, k, v, o, lse, B, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, 0, st);
+    return -2;
+}
+
+extern "C" int pdmk_attn_fwd_causal(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int N,
+                                    int64_t q_bs, int q_ld, int64_t k_bs, int k_ld, int64_t v_bs, int v_ld, int64_t o_bs,
+                                    int o_ld, float scale, int dtype, pdmk_stream stream) {
+    if (!q || !k || !v || !o || !lse || B <= 0 || H <= 0 || N <= 0) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PDMK_BF16)
+        return attn_fwd<bf16>(q, k, v, o, lse, B, H, N, N, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, 1, st);
+    if (dtype == PDMK_F32)
+        return attn_fwd<float>(q, k, v, o, lse, B, H, N, N, q_bs, q_ld, k_bs, k_ld, v_bs, v_ld, o_bs, o_ld, scale, 1, st);
     return -2;
 }
 

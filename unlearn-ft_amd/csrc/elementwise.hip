@@ -67,7 +67,7 @@ int geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, in
 }
 
 // ------------------------------------------------------------------------------------------------ SiLU / AXPBY
-template <typename T, int OP>   // 0 silu fwd, 1 silu bwd (y=dy in, out=dx), 2 axpby
+template <typename T, int OP>   // 0 silu fwd, 1 silu bwd (y=dy in, out=dx), 2 axpby, 3 erf-gelu fwd
 __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* __restrict__ y, long n, float alpha,
                           float beta) {
     constexpr int V = Vec<T>::N;
@@ -82,6 +82,9 @@ __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* _
             Vec<T>::load(a + i * V, o);
 #pragma unroll
             for (int e = 0; e < V; ++e) o[e] *= silu_grad_f(f[e]);
+        } else if (OP == 3) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = gelu_f(f[e]);
         } else {
             Vec<T>::load(y + i * V, o);
 #pragma unroll
@@ -95,6 +98,7 @@ __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* _
         float o;
         if (OP == 0) o = silu_f(f);
         else if (OP == 1) o = to_f32(a[i]) * silu_grad_f(f);
+        else if (OP == 3) o = gelu_f(f);
         else o = alpha * f + beta * to_f32(y[i]);
         y[i] = from_f32<T>(o);
     }
@@ -508,6 +512,12 @@ extern "C" int pdmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n,
     if (!x || !dy || !dx || n <= 0) return -1;
     if (dtype == PDMK_BF16) return ew<bf16, 1>(x, dy, dx, n, 0, 0, (hipStream_t)s);
     if (dtype == PDMK_F32) return ew<float, 1>(x, dy, dx, n, 0, 0, (hipStream_t)s);
+    return -2;
+}
+extern "C" int pdmk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream s) {
+    if (!x || !y || n <= 0) return -1;
+    if (dtype == PDMK_BF16) return ew<bf16, 3>(x, x, y, n, 0, 0, (hipStream_t)s);
+    if (dtype == PDMK_F32) return ew<float, 3>(x, x, y, n, 0, 0, (hipStream_t)s);
     return -2;
 }
 extern "C" int pdmk_axpby(const void* x, void* y, float alpha, float beta, int64_t n, int dtype, pdmk_stream s) {

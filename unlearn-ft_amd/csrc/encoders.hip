@@ -1,9 +1,10 @@
-// Kernels only the VAE encode in front of the step needs (trainer.py:2405-2406):
+// Kernels only the encoders in front of the step need (trainer.py:2405-2406, data_utils.py:155-191):
 //   pdmk_softmax_rows  : row softmax of a materialised fp32 score matrix.  The encoder's one attention layer has a single
 //                        512-wide head over 4096 tokens per image (diffusers AutoencoderKL mid block; CompVis twin
 //                        ldm/modules/diffusionmodules/model.py:150-204): scores are two plain GEMMs per image around this
 //                        pass (the U-Net's flash kernels are specialised for head dim 64).
 //   pdmk_latent_sample : DiagonalGaussianDistribution.sample() * scaling_factor on NHWC moments -> NCHW fp32 latents.
+//   pdmk_embed_tokens  : CLIP text embeddings, token row + position row.
 #include "vec.h"
 
 namespace {
@@ -72,6 +73,27 @@ __global__ __launch_bounds__(NT) void latent_sample_kernel(const T* __restrict__
     }
 }
 
+// out[i, :] = tok[clamp(ids[i]), :] + pos[i % T, :]   (one 16-byte chunk per thread)
+template <typename T>
+__global__ __launch_bounds__(NT) void embed_tokens_kernel(const int64_t* __restrict__ ids, const T* __restrict__ tok,
+                                                          const T* __restrict__ pos, T* __restrict__ out, long ntok, int T_,
+                                                          int D, int vocab, int ldt, int ldp, int ldo) {
+    constexpr int V = Vec<T>::N;
+    const int cpr = D / V;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < ntok * cpr; i += (long)gridDim.x * NT) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr) * V;
+        long id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        float a[V], b[V];
+        Vec<T>::load(tok + id * ldt + c, a);
+        Vec<T>::load(pos + (r % T_) * ldp + c, b);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += b[e];
+        Vec<T>::store(out + r * ldo + c, a);
+    }
+}
+
 template <typename T> int softmax_launch(const float* s, void* p, long rows, int cols, long lds, long ldp, hipStream_t st) {
     T* pt = reinterpret_cast<T*>(p);
     if (cols <= NT * 4) hipLaunchKernelGGL((softmax_rows_kernel<T, 1>), dim3(rows), dim3(NT), 0, st, s, pt, cols, lds, ldp);
@@ -91,6 +113,22 @@ extern "C" int pdmk_softmax_rows(const float* s, void* p, int64_t rows, int cols
         ((uintptr_t)s & 15))
         return -1;
     PDMK_DISPATCH(dtype, softmax_launch, s, p, (long)rows, cols, (long)lds, (long)ldp, (hipStream_t)stream);
+}
+
+extern "C" int pdmk_embed_tokens(const int64_t* ids, const void* tok, const void* pos, void* out, int64_t ntok, int T,
+                                 int D, int vocab, int ldt, int ldp, int ldo, int dtype, pdmk_stream stream) {
+    const int v = dtype == PDMK_BF16 ? 8 : 4;
+    if (!ids || !tok || !pos || !out || ntok <= 0 || T <= 0 || D <= 0 || vocab <= 0 || (D % v) || (ldt % v) || (ldp % v) ||
+        (ldo % v) || (((uintptr_t)tok | (uintptr_t)pos | (uintptr_t)out) & 15))
+        return -1;
+    const long items = ntok * (D / v);
+    dim3 grid((unsigned)((items + NT - 1) / NT < 8192 ? (items + NT - 1) / NT : 8192));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PDMK_BF16) hipLaunchKernelGGL(embed_tokens_kernel<bf16>, grid, dim3(NT), 0, st, ids, (const bf16*)tok, (const bf16*)pos, (bf16*)out, (long)ntok, T, D, vocab, ldt, ldp, ldo);
+    else if (dtype == PDMK_F32) hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, dim3(NT), 0, st, ids, (const float*)tok, (const float*)pos, (float*)out, (long)ntok, T, D, vocab, ldt, ldp, ldo);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int pdmk_latent_sample(const void* moments, int ld, const float* eps, float* latents, int B, int C, int HW,

@@ -79,6 +79,9 @@ _SIGS = {
     "pdmk_skinny_wgrad": ([vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_softmax_rows": ([vp, vp, i64, i32, i64, i64, i32, vp], i32),
     "pdmk_latent_sample": ([vp, i32, vp, vp, i32, i32, i32, f32, i32, vp], i32),
+    "pdmk_embed_tokens": ([vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_attn_fwd_causal": ([vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
+    "pdmk_gelu_fwd": ([vp, vp, i64, i32, vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
     _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
@@ -340,6 +343,21 @@ def add_noise_velocity(x0, noise, t, sa, sb, noisy, target, B, Cc, HW, cpad):
 
 def nchw_to_nhwc(src, dst, B, Cc, HW, cpad):
     _chk(_lib.pdmk_nchw_to_nhwc(_p(src), _p(dst), B, Cc, HW, cpad, dt(dst), _st()), "pdmk_nchw_to_nhwc")
+
+
+def embed_tokens(ids, tok, pos, out, ntok, T, D, vocab, ldt, ldp, ldo):
+    _chk(_lib.pdmk_embed_tokens(_p(ids), _p(tok), _p(pos), _p(out), ntok, T, D, vocab, ldt, ldp, ldo, dt(out), _st()),
+         "pdmk_embed_tokens")
+
+
+def attn_fwd_causal(q, kk, v, o, lse, B, H, N, qs, ks, vs, os_, scale):
+    """qs / ks / vs / os_ = (batch stride, row stride) in elements, as attn_fwd."""
+    _chk(_lib.pdmk_attn_fwd_causal(_p(q), _p(kk), _p(v), _p(o), _p(lse), B, H, N, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1],
+                                   os_[0], os_[1], float(scale), dt(q), _st()), "pdmk_attn_fwd_causal")
+
+
+def gelu_fwd(x, y):
+    _chk(_lib.pdmk_gelu_fwd(_p(x), _p(y), x.numel(), dt(x), _st()), "pdmk_gelu_fwd")
 
 
 def softmax_rows(s, p, rows, cols, lds, ldp):
