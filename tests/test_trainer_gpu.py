@@ -75,3 +75,29 @@ def test_pixel_batches_go_through_the_vae(dev, tmp_path):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
     with pytest.raises(KeyError):
         tr.step({"prompt_embeds": batch["prompt_embeds"]})
+
+
+def test_token_id_batches_go_through_the_text_encoder(dev, tmp_path):
+    """`input_ids` / `empty_input_ids` batches: prompt_embeds = text_encoder(ids)[0] (data_utils.py:155-191) computed once
+    per step on the device; the empty prompt is encoded once and cached; same losses as with the embeddings handed over."""
+    from pdm.training.trainer import BilevelUnetFineTuner
+    cfg = _config(tmp_path, 1)
+    tr = BilevelUnetFineTuner(cfg)
+    b0 = next(iter(tr.train_dataloader))
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 1000, (2, 13), generator=g)
+    empty = torch.tensor([[3] + [0] * 12]).expand(2, -1)
+    batch = {"latents": b0["latents"], "input_ids": ids, "empty_input_ids": empty}
+    st = tr.rng.get_state()
+    loss = tr.upper_step(batch)
+    assert all(torch.isfinite(x).all() for x in loss)
+    assert len(tr._empty_cache) == 1
+    tr.upper_step(batch)
+    assert len(tr._empty_cache) == 1                          # cached: not encoded again
+    tr2 = BilevelUnetFineTuner(cfg)
+    tr2.rng.set_state(st)
+    pe, ee = tr2.text_encoder(ids)[0], tr2.text_encoder(empty)[0]
+    assert pe.shape == (2, 13, 64)
+    loss2 = tr2.upper_step({"latents": b0["latents"], "prompt_embeds": pe, "empty_prompt_embeds": ee})
+    for a, b in zip(loss, loss2):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)

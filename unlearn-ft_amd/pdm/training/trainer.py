@@ -8,7 +8,9 @@ Differences that are deliberate:
    reference's key names (trainer.py:2819-2834) and are read back asynchronously (no per-step .item() syncs);
  * batches carry the reference's `pixel_values` (encoded by the frozen VAE on libpdmk, trainer.py:2405-2406) or
    pre-encoded `latents`; `--synthetic` produces seeded batches of either kind (`synthetic_pixels: true` for pixels);
-   the CLIP text encoder of the dataset transform is SURVEY 8f row N2 (not built): batches carry `prompt_embeds`;
+   text conditioning comes as the reference's `prompt_embeds` / `empty_prompt_embeds`, or as token ids (`input_ids` /
+   `empty_input_ids`) encoded here by the frozen CLIP text encoder on libpdmk (data_utils.py:155-191) - one batched
+   call per step instead of two per sample inside the dataloader, the empty-prompt embedding cached per distinct row;
  * torch.autograd.set_detect_anomaly (scripts/aptp/*.py:21) is not reproduced.
 """
 import glob
@@ -96,6 +98,42 @@ class Trainer:
                                                       vae_config=vcfg, torch_dtype=self.weight_dtype, device=self.device)
         return self._vae
 
+    # ---- frozen CLIP text encoder (trainer.py:2126-2131); built on first use
+    @property
+    def text_encoder(self):
+        if getattr(self, "_text_encoder", None) is None:
+            from ..models.clip.text_encoder import CLIPTextModel, CLIPTextConfig
+            root = _cfg(self.config, "pretrained_model_name_or_path")
+            local = bool(root) and os.path.isdir(os.path.join(root, "text_encoder"))
+            tcfg = None
+            if _cfg(self.config, "tiny", False):
+                tcfg = CLIPTextConfig(vocab_size=1000, hidden_size=self.unet_config.cross_attention_dim, intermediate_size=256,
+                                      num_hidden_layers=2, num_attention_heads=self.unet_config.cross_attention_dim // 64)
+            self._text_encoder = CLIPTextModel.from_pretrained(root if local else None, subfolder="text_encoder",
+                                                               random_init=not local, text_config=tcfg,
+                                                               torch_dtype=self.weight_dtype, device=self.device)
+            self._empty_cache = {}
+        return self._text_encoder
+
+    def _prompt_embeds(self, batch, empty=False):
+        """`prompt_embeds` / `empty_prompt_embeds` as given, else encoded from `input_ids` / `empty_input_ids`."""
+        key, ids_key = ("empty_prompt_embeds", "empty_input_ids") if empty else ("prompt_embeds", "input_ids")
+        if key in batch:
+            return batch[key]
+        if ids_key not in batch:
+            raise KeyError(f"batch has neither {key!r} nor {ids_key!r}")
+        ids = batch[ids_key]
+        enc = self.text_encoder
+        if not empty:
+            return enc(ids)[0]
+        # the empty prompt is one token row repeated over the batch (data_utils.py:272-274): encode it once, ever
+        row = tuple(ids[0].tolist())
+        if not bool((ids == ids[:1]).all()):
+            return enc(ids)[0]
+        if row not in self._empty_cache:
+            self._empty_cache[row] = enc(ids[:1])[0]
+        return self._empty_cache[row].expand(ids.shape[0], -1, -1).contiguous()
+
     # ---- trainer.py:516-527: student master weights fp32; bf16 compute under mixed precision
     def init_weight_dtype(self):
         mp = _cfg(self.config, "mixed_precision", None) or _cfg(self.config, "training.mixed_precision", None)
@@ -168,8 +206,9 @@ class Trainer:
         c = self.config
         if not _cfg(c, "synthetic", False):
             raise NotImplementedError(
-                "image datasets + CLIP text encoding are SURVEY 8f row N2 (not built yet): pass a dataloader yielding "
-                "{'pixel_values' or 'latents', 'prompt_embeds', 'empty_prompt_embeds'} or run with --synthetic")
+                "image datasets and tokenisation are host-side data loading (not built): pass a dataloader yielding "
+                "{'pixel_values' | 'latents', 'prompt_embeds' | 'input_ids', 'empty_prompt_embeds' | 'empty_input_ids'} "
+                "or run with --synthetic")
         bs = int(_cfg(c, "data.dataloader.train_batch_size", 8))
         res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
         seed = int(_cfg(c, "seed", 43)) + self.rank + (7919 if upper else 0)
@@ -195,7 +234,7 @@ class Trainer:
 
     def step(self, batch):
         lat, noise, t = self._sample(batch)
-        L = self.stepper.main_step(lat, noise, t, batch["prompt_embeds"])
+        L = self.stepper.main_step(lat, noise, t, self._prompt_embeds(batch))
         return self._tuple(L, upper=False)
 
     def _tuple(self, L, upper):
@@ -263,7 +302,7 @@ class UnetFineTuner(Trainer):
         for batch in self.train_dataloader:
             if self.global_step >= max_steps:
                 break
-            if batch["prompt_embeds"].numel() == 0:          # empty batch is skipped (trainer.py:2771-2772)
+            if batch.get("prompt_embeds", batch.get("input_ids")).numel() == 0:   # empty batch is skipped (trainer.py:2771-2772)
                 continue
             loss = self.step(batch)
             lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
@@ -310,7 +349,7 @@ class BilevelUnetFineTuner(UnetFineTuner):
 
     def upper_step(self, batch):
         lat, noise, t = self._sample(batch)
-        L = self.stepper.upper_step(lat, noise, t, batch["prompt_embeds"], batch["empty_prompt_embeds"])
+        L = self.stepper.upper_step(lat, noise, t, self._prompt_embeds(batch), self._prompt_embeds(batch, empty=True))
         return self._tuple(L, upper=True)
 
 
