@@ -197,6 +197,14 @@ def main():
                 vae.encode_latents(px)
             extras["ms_vae_encode_untimed"] = round(timed(lambda j: vae.encode_latents(px), 3) * 1e3, 2)
             del vae, px
+            # SURVEY 8f N2, same status: prompt_embeds = text_encoder(input_ids)[0] for the batch's captions (77 tokens)
+            from pdm.models.clip.text_encoder import CLIPTextModel
+            txt = CLIPTextModel(None, dev, dtype, seed=0)
+            tok = torch.randint(0, txt.cfg.vocab_size, (B, 77), device=dev)
+            for _ in range(2):
+                txt(tok)
+            extras["ms_text_encode_untimed"] = round(timed(lambda j: txt(tok), 5) * 1e3, 3)
+            del txt, tok
         n_upper = sum(1 for i in range(a.steps) if (i + 1) % a.upper_freq == 0)
         flop_main = 2.0 * (Tm + 3 * Sm) * B
         flop_upper = 2.0 * (2 * Tm + 3 * Sm) * B

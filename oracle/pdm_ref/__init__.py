@@ -11,6 +11,8 @@ against the reference pieces that DO import (``oracle/validate_against_reference
 hard_concrete, gates, and the vendored CompVis ResBlock / SpatialTransformer / Downsample / Upsample /
 timestep_embedding / make_beta_schedule twins; known-answer vectors are committed under tests/golden/.
 ``vae.py`` (the VAE encode in front of the step) is pinned the same way against the vendored CompVis
-Encoder / AttnBlock / Downsample / DiagonalGaussianDistribution (``oracle/validate_vae_against_reference.py``).
+Encoder / AttnBlock / Downsample / DiagonalGaussianDistribution (``oracle/validate_vae_against_reference.py``);
+``clip_text.py`` (row N2, the text encoder of the dataset transform) against ``transformers.CLIPTextModel`` itself, the
+third-party class the reference instantiates (``oracle/validate_clip_against_transformers.py``).
 """
 from .config import UNetConfig  # noqa: F401
