@@ -242,6 +242,29 @@ def main():
                           f"igemm_kernel<__bf16, {kd[1]}, {kd[2]}, 0, 8, 8> [rocprofv3: {legacy_sym.get(kd[1:3], 'igemm_kernel / pdmk_dma::igemm_dma_kernel')}]")
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
+
+        # Two-sided roofline per launch: a GEMM cannot finish before max(MACs / MFMA peak, algorithmic bytes / HBM peak).
+        # Algorithmic bytes = each operand once (a conv's input image once, not once per tap) + the output once.  The
+        # K = 320 .. 640 Linear layers at 64^2 latents sit BELOW the ridge point (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): for
+        # them the HBM side is the binding one, which the single MFMA fraction above cannot show.
+        def two_sided(entries):
+            esz = 2 if a.dtype == "bf16" else 4
+            pk = (2500e12 if a.dtype == "bf16" else 157.3e12)
+            t_m = t_h = t_r = t_meas = 0.0
+            n_h = 0
+            for kind, flops, e0, e1, (M, N, K, sk) in entries:
+                conv_a, wg = kind[1] == 1, kind[1] == 2
+                if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
+                    byts = esz * (K * M + K * (N // 9 if kind[2] == 2 else N)) + 4 * M * N
+                else:
+                    byts = esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
+                tm, th = 2.0 * M * N * K / pk, byts / 8e12
+                t_m, t_h, t_r = t_m + tm, t_h + th, t_r + max(tm, th)
+                n_h += th > tm
+                t_meas += e0.elapsed_time(e1) * 1e-3
+            return {"mfma_floor_ms": round(t_m * 1e3, 3), "hbm_floor_ms": round(t_h * 1e3, 3),
+                    "roofline_floor_ms": round(t_r * 1e3, 3), "measured_ms": round(t_meas * 1e3, 3),
+                    "frac": round(t_r / t_meas, 4), "launches": len(entries), "hbm_bound_launches": int(n_h)}
         peak = 2500.0 if a.dtype == "bf16" else 157.3
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
@@ -255,6 +278,9 @@ def main():
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r01_pmc_hbm_traffic.json)",
                 "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
+                "two_sided": {"note": "per launch max(MACs/2.5 PFLOP/s, algorithmic bytes/8 TB/s) summed, over measured time",
+                              "dominant_kernel": two_sided([p_ for p_ in prof if p_[0] == dom[0]]),
+                              "all_gemms": two_sided(prof)},
                 "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),
                 "gemm_classes": {class_names[kd[1:3]]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 2),
                                                         "launches": v[2]} for kd, v in cls.items()},
