@@ -1,4 +1,4 @@
-"""Functional fp32 AutoencoderKL *encoder* on a state dict (oracle side, NCHW, plain torch) - SURVEY 8f row N1.
+"""Functional fp32 AutoencoderKL encoder and decoder (row N3) on a state dict (oracle side, NCHW).
 
 What the reference runs right before the U-Net (pdm/training/trainer.py:2405-2406):
     latents = vae.encode(pixel_values).latent_dist.sample() * vae.config.scaling_factor
@@ -11,6 +11,9 @@ container; the twin that IS importable is the CompVis encoder the diffusers clas
 and the key-name correspondence CompVis -> diffusers is the reference's own converter
     baselines/.../train-scripts/convertModels.py:481-600 (convert_ldm_vae_checkpoint).
 `oracle/validate_vae_against_reference.py` pins this file against those twins.  State-dict keys are the diffusers ones.
+Decoder (image logging / FID sampling, pdm/pipelines/pruning_pipelines.py:993-995: vae.decode(latents / scaling_factor)):
+twin Decoder model.py:462-569, Upsample (nearest x2 + conv) :42-58; diffusers order up_blocks[i] = CompVis up[n-1-i]
+(convertModels.py:555-580).
 """
 from dataclasses import dataclass
 from typing import Tuple
@@ -80,6 +83,25 @@ def encode_moments(sd, cfg: VAEConfig, x):
     return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
 
 
+def decode(sd, cfg: VAEConfig, z):
+    """latents [B, latent, h, w] (already divided by scaling_factor) -> image [B, 3, 8h.., ..] = decoder(post_quant_conv(z))."""
+    G, eps = cfg.norm_num_groups, cfg.eps
+    h = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    h = F.conv2d(h, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    h = resnet(sd, "decoder.mid_block.resnets.0", h, G, eps)
+    h = mid_attention(sd, "decoder.mid_block.attentions.0", h, G, eps)
+    h = resnet(sd, "decoder.mid_block.resnets.1", h, G, eps)
+    n = len(cfg.block_out_channels)
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            h = resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", h, G, eps)
+        if i != n - 1:
+            p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+            h = F.conv2d(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd[p + ".weight"], sd[p + ".bias"], padding=1)
+    h = F.silu(F.group_norm(h, G, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], eps))
+    return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
 def sample_latents(moments, eps_noise, scaling_factor):
     """latent_dist.sample() * scaling_factor with the Gaussian draw `eps_noise` supplied (distributions.py:24-37)."""
     mean, logvar = torch.chunk(moments, 2, dim=1)
@@ -133,4 +155,23 @@ def init_state_dict(cfg: VAEConfig, seed=0, jitter=True):
     norm("encoder.conv_norm_out", cin)
     conv("encoder.conv_out", 2 * cfg.latent_channels, cin, 3)
     conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    # decoder half (drawn after the encoder so the encoder's weights do not depend on it)
+    conv("post_quant_conv", cfg.latent_channels, cfg.latent_channels, 1)
+    rev = tuple(reversed(ch))
+    conv("decoder.conv_in", rev[0], cfg.latent_channels, 3)
+    res("decoder.mid_block.resnets.0", rev[0], rev[0])
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", rev[0])
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        lin(f"{a}.{nm}", rev[0], rev[0])
+    res("decoder.mid_block.resnets.1", rev[0], rev[0])
+    cin = rev[0]
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin, co)
+            cin = co
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co, 3)
+    norm("decoder.conv_norm_out", cin)
+    conv("decoder.conv_out", cfg.in_channels, cin, 3)
     return sd

@@ -23,7 +23,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(REF, "baselines/erasing/oldcode_erasing_compvis"))
 
 from pdm_ref import vae  # noqa: E402
-from ldm.modules.diffusionmodules.model import Encoder, AttnBlock, Downsample  # noqa: E402
+from ldm.modules.diffusionmodules.model import Encoder, Decoder, AttnBlock, Downsample  # noqa: E402
 from ldm.modules.distributions.distributions import DiagonalGaussianDistribution  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -53,12 +53,23 @@ def twin_key(k):
     return k
 
 
-def load_twin(enc, sd):
+def twin_key_dec(k, nlev):
+    """diffusers decoder key -> CompVis Decoder key: up_blocks[i] = up[nlev-1-i] (convertModels.py:555-580)."""
+    k = "encoder." + k[len("decoder."):]                  # reuse the shared renames, then fix the up path
+    if k.startswith("encoder.up_blocks."):
+        _, _, i, kind, j, rest = k.split(".", 5)
+        lvl = nlev - 1 - int(i)
+        rest = rest.replace("conv_shortcut", "nin_shortcut")
+        return f"up.{lvl}.block.{j}.{rest}" if kind == "resnets" else f"up.{lvl}.upsample.{rest}"
+    return twin_key(k)
+
+
+def load_twin(enc, sd, prefix="encoder.", nlev=0):
     tsd = {}
     for k, v in sd.items():
-        if not k.startswith("encoder."):
+        if not k.startswith(prefix):
             continue
-        tk = twin_key(k)
+        tk = twin_key(k) if prefix == "encoder." else twin_key_dec(k, nlev)
         if ".attn_1." in tk and tk.endswith(".weight") and v.dim() == 2:
             v = v[:, :, None, None]                      # the twin's q/k/v/proj_out are 1x1 convs
         tsd[tk] = v
@@ -87,6 +98,16 @@ for tag, cfg, res, B in (("tiny", vae.VAEConfig.tiny(), 32, 2),
     torch.manual_seed(5)
     eps = torch.randn(dist.mean.shape)
     ok(f"DiagonalGaussian[{tag}] sample", vae.sample_latents(mom_ref * 4.0, eps, 1.0), z_ref, 1e-6)
+    # decoder half: post_quant_conv + Decoder on seeded latents
+    dec = Decoder(ch=ch[0], out_ch=3, ch_mult=tuple(c // ch[0] for c in ch), num_res_blocks=cfg.layers_per_block,
+                  attn_resolutions=[], in_channels=3, resolution=res, z_channels=cfg.latent_channels)
+    load_twin(dec, sd, prefix="decoder.", nlev=len(ch))
+    zin = torch.randn(B, cfg.latent_channels, *mom_ref.shape[2:], generator=g)
+    with torch.no_grad():
+        img_ref = dec(torch.nn.functional.conv2d(zin, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]))
+        img = vae.decode(sd, cfg, zin)
+    ok(f"post_quant_conv + Decoder[{tag}] image", img, img_ref, 2e-5)
+    golden[f"{tag}_zin"], golden[f"{tag}_img"] = zin.numpy(), img_ref.numpy()
     golden[f"{tag}_x"], golden[f"{tag}_moments"] = x.numpy(), mom_ref.numpy()
     golden[f"{tag}_eps"], golden[f"{tag}_z4"] = eps.numpy(), z_ref.numpy()
 

@@ -1,4 +1,5 @@
-"""`AutoencoderKL` (encode half) on libpdmk - the step right in front of the U-Net boundary.
+"""`AutoencoderKL` on libpdmk: encode = the step right in front of the U-Net boundary; decode = the last
+stage of the image-logging / FID sampler (row N3, pdm/pipelines/pruning_pipelines.py:993-995).
 
 What the reference does with diffusers' AutoencoderKL (pdm/training/trainer.py:2405-2406, frozen, cast to the weight
 dtype at :516-527, 2730-2733):
@@ -39,7 +40,7 @@ class VAEConfig:
         return VAEConfig()
 
 
-def build_entries(cfg: VAEConfig):
+def build_entries(cfg: VAEConfig, decoder=True):
     E = []
 
     def conv(key, co, ci):
@@ -78,6 +79,26 @@ def build_entries(cfg: VAEConfig):
     norm("encoder.conv_norm_out", cin)
     conv("encoder.conv_out", 2 * cfg.latent_channels, cin)
     lin("quant_conv", [("quant_conv", 2 * cfg.latent_channels)], 2 * cfg.latent_channels)
+    if decoder:        # diffusers Decoder: mid block first, then up_blocks over reversed(block_out_channels), 3 ResBlocks each
+        lin("post_quant_conv", [("post_quant_conv", cfg.latent_channels)], cfg.latent_channels)
+        rev = tuple(reversed(ch))
+        conv("decoder.conv_in", rev[0], cfg.latent_channels)
+        res("decoder.mid_block.resnets.0", rev[0], rev[0])
+        a = "decoder.mid_block.attentions.0"
+        norm(a + ".group_norm", rev[0])
+        lin(a + ".to_qk", [(a + ".to_q", rev[0]), (a + ".to_k", rev[0])], rev[0])
+        lin(a + ".to_v", [(a + ".to_v", rev[0])], rev[0])
+        lin(a + ".to_out.0", [(a + ".to_out.0", rev[0])], rev[0])
+        res("decoder.mid_block.resnets.1", rev[0], rev[0])
+        cin = rev[0]
+        for i, co in enumerate(rev):
+            for j in range(cfg.layers_per_block + 1):
+                res(f"decoder.up_blocks.{i}.resnets.{j}", cin, co)
+                cin = co
+            if i != len(rev) - 1:
+                conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co)
+        norm("decoder.conv_norm_out", cin)
+        conv("decoder.conv_out", cfg.in_channels, cin)
     off = 0
     for e in E:
         e.off = off
@@ -129,13 +150,14 @@ class _LatentDist:
 
 
 class AutoencoderKL:
-    def __init__(self, cfg: VAEConfig = None, device=None, dtype=torch.bfloat16, seed=0, init=True):
+    def __init__(self, cfg: VAEConfig = None, device=None, dtype=torch.bfloat16, seed=0, init=True, decoder=True):
         if not torch.cuda.is_available():
             raise RuntimeError("AutoencoderKL (MI355X engine) needs a GPU; there is no CPU fallback")
         self.cfg = cfg or VAEConfig.sd21()
         self.device = torch.device(device or "cuda:0")
         self.dtype = dtype
-        self.store = ParamStore(build_entries(self.cfg), self.device, dtype, train=False)
+        self.has_decoder = decoder
+        self.store = ParamStore(build_entries(self.cfg, decoder), self.device, dtype, train=False)
         self.ops = _Ops(self.store, dtype)
         self.config = SimpleNamespace(scaling_factor=self.cfg.scaling_factor, latent_channels=self.cfg.latent_channels,
                                       block_out_channels=self.cfg.block_out_channels, in_channels=self.cfg.in_channels)
@@ -165,13 +187,14 @@ class AutoencoderKL:
         return model
 
     def load_state_dict(self, sd, strict=True):
-        """diffusers AutoencoderKL keys; decoder / post_quant_conv keys are ignored (encode half only); the pre-0.14
+        """diffusers AutoencoderKL keys (decoder / post_quant_conv keys are ignored when built with decoder=False); the pre-0.14
         attention names (query/key/value/proj_attn, still written by the reference's converter,
         baselines/erasing/oldcode_erasing_compvis/train-scripts/convertModels.py:120-140) are accepted."""
         ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
         own = {}
         for key, v in sd.items():
-            if not (key.startswith("encoder.") or key.startswith("quant_conv.")):
+            if not (key.startswith("encoder.") or key.startswith("quant_conv.") or
+                    (self.has_decoder and (key.startswith("decoder.") or key.startswith("post_quant_conv.")))):
                 continue
             parts = key.split(".")
             if "attentions" in parts and parts[-2] in ren:
@@ -181,8 +204,9 @@ class AutoencoderKL:
 
     def state_dict(self):
         sd = self.store.state_dict()
-        for key in ("quant_conv.weight",):
-            sd[key] = sd[key].reshape(*sd[key].shape, 1, 1)
+        for key in ("quant_conv.weight", "post_quant_conv.weight"):
+            if key in sd:
+                sd[key] = sd[key].reshape(*sd[key].shape, 1, 1)
         return sd
 
     def requires_grad_(self, flag=False):
@@ -253,6 +277,35 @@ class AutoencoderKL:
         h, _, _ = o.conv3(h, "encoder.conv_out", B, H, W, 0, "encoder.conv_out.bias")
         mom = o.linear(h, "quant_conv", bias="quant_conv.bias")
         return mom.t, B, H, W
+
+    def decode(self, z, return_dict=True):
+        """latents [B, 4, h, w] NCHW (already divided by scaling_factor, as pruning_pipelines.py:994 passes them) ->
+        `.sample` image [B, 3, 8h, 8w] NCHW fp32 = decoder(post_quant_conv(z))."""
+        if not self.has_decoder:
+            raise RuntimeError("this AutoencoderKL was built with decoder=False")
+        B, C, H, W = z.shape
+        assert C == self.cfg.latent_channels
+        o, G = self.ops, self.cfg.norm_num_groups
+        cp = padc(C)
+        x = torch.empty((B * H * W, cp), device=self.device, dtype=self.dtype)
+        k.nchw_to_nhwc(z.to(self.device, torch.float32).contiguous(), x, B, C, H * W, cp)
+        h = o.linear(Act(x, rg=False), "post_quant_conv", bias="post_quant_conv.bias")
+        h, _, _ = o.conv3(h, "decoder.conv_in", B, H, W, 0, "decoder.conv_in.bias")
+        h = self._res("decoder.mid_block.resnets.0", h, B, H, W)
+        h = self._attn("decoder.mid_block.attentions.0", h, B, H * W)
+        h = self._res("decoder.mid_block.resnets.1", h, B, H, W)
+        n = len(self.cfg.block_out_channels)
+        for i in range(n):
+            for j in range(self.cfg.layers_per_block + 1):
+                h = self._res(f"decoder.up_blocks.{i}.resnets.{j}", h, B, H, W)
+            if i != n - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                h, H, W = o.conv3(h, p, B, H, W, 2, p + ".bias")            # nearest x2 fused into the conv's gather
+        h = o.groupnorm(h, "decoder.conv_norm_out", B, H * W, G, h.t.shape[1] // G, self.cfg.eps, True)
+        h, _, _ = o.conv3(h, "decoder.conv_out", B, H, W, 0, "decoder.conv_out.bias")
+        img = torch.empty((B, self.cfg.in_channels, H, W), device=self.device, dtype=torch.float32)
+        k.nhwc_to_nchw(h.t, img, B, self.cfg.in_channels, H * W, _ld(h.t))
+        return SimpleNamespace(sample=img) if return_dict else (img,)
 
     def encode(self, pixel_values, return_dict=True):
         mom, B, H, W = self.encode_moments(pixel_values)
