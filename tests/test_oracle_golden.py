@@ -105,3 +105,34 @@ def test_clip_text_oracle_matches_transformers_outputs():
     ids[0, 40:] = 7
     b = clip_text.encode(sd, cfg, ids)
     assert torch.allclose(a[0, :40], b[0, :40], atol=1e-6) and not torch.allclose(a[0, 40:], b[0, 40:], atol=1e-3)
+
+
+# ---------------------------------------------------------------- PNDM restatement (parity unpinned: closed forms only)
+def test_pndm_reduces_to_ddim_and_reproduces_constant_predictions():
+    from pdm_ref.sampler import PNDM
+    for pt in ("epsilon", "v_prediction"):
+        s = PNDM(prediction_type=pt)
+        s.set_timesteps(50)
+        assert len(s.timesteps) == 51 and s.timesteps[0] == 981 and s.timesteps[1] == 961 and s.timesteps[2] == 961
+        assert s.timesteps[-1] == 1
+        g = torch.Generator().manual_seed(0)
+        x, out = torch.randn(2, 4, 8, 8, generator=g).double(), torch.randn(2, 4, 8, 8, generator=g).double()
+        t, pt_ = 601, 581
+        a_t, a_p = s.ac[t], s.ac[pt_]
+        eps = out if pt == "epsilon" else a_t.sqrt() * out + (1 - a_t).sqrt() * x
+        x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+        ddim = a_p.sqrt() * x0 + (1 - a_p).sqrt() * eps                   # deterministic DDIM step (eta = 0)
+        assert torch.allclose(s.get_prev_sample(x, t, pt_, out), ddim, atol=1e-10)
+        # constant prediction: every Adams-Bashforth combination returns it (weights sum to one), so the walk equals DDIM
+        c = torch.randn(1, 4, 4, 4, generator=g)
+        s.set_timesteps(10)
+        lat, ref = torch.randn(1, 4, 4, 4, generator=g), None
+        ref = lat.double()
+        seen = []
+        for i, tt in enumerate(s.timesteps):
+            lat = s.step(c, tt, lat)
+            seen.append(tt)
+        # DDIM walk over the distinct timesteps 901, 801, ..., 1 -> -99 (final alpha)
+        for tt in sorted(set(seen), reverse=True):
+            ref = PNDM(prediction_type=pt).get_prev_sample(ref, tt, tt - 100, c.double())
+        assert torch.allclose(lat.double(), ref, atol=1e-5), pt
