@@ -14,5 +14,7 @@ timestep_embedding / make_beta_schedule twins; known-answer vectors are committe
 Encoder / AttnBlock / Downsample / DiagonalGaussianDistribution (``oracle/validate_vae_against_reference.py``);
 ``clip_text.py`` (row N2, the text encoder of the dataset transform) against ``transformers.CLIPTextModel`` itself, the
 third-party class the reference instantiates (``oracle/validate_clip_against_transformers.py``).
+``sampler.py`` (row N3): the VAE decoder is pinned like the encoder; the PNDM scheduler is PARITY UNPINNED (diffusers
+absent, no vendored twin) - restated from the published algorithm and checked against the closed forms it must reproduce.
 """
 from .config import UNetConfig  # noqa: F401
