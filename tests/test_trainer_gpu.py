@@ -101,3 +101,60 @@ def test_token_id_batches_go_through_the_text_encoder(dev, tmp_path):
     loss2 = tr2.upper_step({"latents": b0["latents"], "prompt_embeds": pe, "empty_prompt_embeds": ee})
     for a, b in zip(loss, loss2):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_local_snapshot_and_pruning_checkpoint_flow_in(dev, tmp_path):
+    """a local model directory laid out like the hub snapshot the reference loads (trainer.py:2126-2176:
+    unet/, vae/, text_encoder/ safetensors under diffusers / transformers key names) plus a pruning checkpoint
+    (`quantizer_embeddings.pt[expert_id]`, trainer.py:2159-2161) build the same models as handing the tensors over."""
+    from safetensors.torch import save_file
+    from pdm_ref import arch as oarch, weights as oweights, vae as ovae, clip_text
+    from pdm_ref.config import UNetConfig as OCfg
+    from pdm.training.trainer import BilevelUnetFineTuner
+    root, ck = tmp_path / "snapshot", tmp_path / "pruning"
+    for d in (root / "unet", root / "vae", root / "text_encoder", ck):
+        d.mkdir(parents=True)
+    ocfg = OCfg.tiny()
+    dense = oweights.init_dense_state_dict(ocfg, seed=11)
+    save_file({n: t.contiguous() for n, t in dense.items()}, str(root / "unet" / "diffusion_pytorch_model.safetensors"))
+    vcfg = ovae.VAEConfig.tiny()
+    vsd = ovae.init_state_dict(vcfg, seed=12)
+    save_file({n: t.contiguous() for n, t in vsd.items()}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+    tcfg = clip_text.CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=256, num_hidden_layers=2,
+                                    num_attention_heads=1)
+    tsd = clip_text.init_state_dict(tcfg, seed=13, prefix="text_model.")
+    save_file({n: t.contiguous() for n, t in tsd.items()}, str(root / "text_encoder" / "model.safetensors"))
+    experts = torch.stack([oarch.random_arch_vector(ocfg, kr, seed=s)[0] for s, kr in ((1, 0.5), (2, 0.7), (3, 0.9))])
+    torch.save(experts, str(ck / "quantizer_embeddings.pt"))
+    cfg = _config(tmp_path / "logs", 1)
+    cfg["pretrained_model_name_or_path"], cfg["pruning_ckpt_dir"], cfg["expert_id"] = str(root), str(ck), 1
+    tr = BilevelUnetFineTuner(cfg)
+    assert torch.equal(tr.arch_vector, experts[1][None])
+    # student = dense weights physically pruned by expert 1's arch vector; teacher = the dense weights
+    psd, _ = oweights.prune_state_dict(dense, ocfg, experts[1][None])
+    got = tr.prediction_model.state_dict()
+    assert set(got) == set(psd) and all(torch.equal(got[n], psd[n]) for n in psd)
+    tt = tr.teacher_model.state_dict()
+    assert all(torch.equal(tt[n], dense[n]) for n in dense)
+    # frozen encoders come from the same snapshot
+    vs = tr.vae.state_dict()
+    assert all(torch.equal(vs[n], vsd[n]) for n in vsd)
+    ts = tr.text_encoder.state_dict()
+    assert all(torch.equal(ts[n], tsd[n]) for n in tsd)
+    # one step on the reference's raw batch schema (pixels + token ids), then the written checkpoint reloads bit-exactly
+    g = torch.Generator().manual_seed(0)
+    batch = {"pixel_values": torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, "input_ids": torch.randint(0, 1000, (2, 13), generator=g),
+             "empty_input_ids": torch.zeros(2, 13, dtype=torch.int64)}
+    loss = tr.step(batch)
+    tr.stepper.optimizer_step(upper=False)
+    up = tr.upper_step(batch)
+    assert all(torch.isfinite(x).all() for x in loss + up)
+    tr.global_step = 1
+    tr.save_checkpoint()
+    from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+    from pdm.models.unet.spec import UNetConfig
+    re = UNet2DConditionModelPruned.from_pretrained(str(tmp_path / "logs" / "checkpoint-1"), subfolder="unet",
+                                                    unet_config=UNetConfig.tiny(), torch_dtype=torch.bfloat16, device=dev)
+    assert torch.equal(re.arch_vector, tr.arch_vector)
+    a, b = tr.prediction_model.state_dict(), re.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[n], b[n]) for n in a)
