@@ -13,7 +13,7 @@ import os
 import torch
 
 from ... import _pdmk as k
-from .params import ParamStore, temb_layout
+from .params import ParamStore, kv_layout, temb_layout
 from .spec import UNetConfig, padc
 
 
@@ -45,6 +45,7 @@ class UNetEngine:
         # weight-gradient GEMMs only feed the optimiser: they run on a side stream (a parallel branch of the captured
         # graph) next to the dgrad chain, which is the critical path of the backward pass
         self.temb_lay, self.temb_cols = temb_layout(cfg, blocks)
+        self.kv_lay, self.kv_cols = kv_layout(blocks)
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -358,10 +359,9 @@ class UNetEngine:
         h = self.linear(o, t + ".attn1.to_out.0", bias=t + ".attn1.to_out.0.bias", residual=h)
         l2 = self.layernorm(h, t + ".norm2")
         q = self.linear(l2, t + ".attn2.to_q")
-        kv = self.linear(ehs, t + ".attn2.to_kv")
-        kv.rg = self.train
-        o = self.attention(q.t[:, :d2], kv.t[:, :d2], kv.t[:, d2:2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
-                           ((0, d2), (d2, 2 * d2)))
+        kv, ko = ehs, self.kv_lay[p][0]      # `ehs` = the batched K/V projection of all transformers; this one's columns
+        o = self.attention(q.t[:, :d2], kv.t[:, ko:ko + d2], kv.t[:, ko + d2:ko + 2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
+                           ((ko, ko + d2), (ko + d2, ko + 2 * d2)))
         h = self.linear(o, t + ".attn2.to_out.0", bias=t + ".attn2.to_out.0.bias", residual=h)
         l3 = self.layernorm(h, t + ".norm3")
         f = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias")
@@ -386,6 +386,9 @@ class UNetEngine:
         if self.temb_cols:                        # all time_emb_proj in one skinny GEMM; ResBlocks take column slices
             st = self.linear(st, "time_emb_proj_all", bias="time_emb_proj_all.bias", out_f32=True)
         ehs_act = Act(ehs, rg=False)
+        if self.kv_cols:                          # all cross-attention K/V projections in one GEMM; layers take column slices
+            ehs_act = self.linear(ehs_act, "attn2_kv_all")
+            ehs_act.rg = train
         h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias")
         skips = [h]
         acts = {}

@@ -80,6 +80,20 @@ def temb_layout(cfg: UNetConfig, blocks):
     return lay, off
 
 
+def kv_layout(blocks):
+    """Column layout of the ONE batched cross-attention K/V projection: every transformer's attn2.to_k / to_v
+    (blocks.py:244-285) reads the same prompt embeddings, so their weights are row blocks of one [sum 2 d2, ctx] matrix:
+    {transformer name: (first column, d2)} with K at [off, off + d2) and V at [off + d2, off + 2 d2), and the total width."""
+    off, lay = 0, {}
+    for b in blocks:
+        for a in b.attns:
+            if not a.dropped:
+                d2 = a.h2() * 64
+                lay[a.name] = (off, d2)
+                off += 2 * d2
+    return lay, off
+
+
 def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
     G = cfg.norm_num_groups
     E: List[Entry] = []
@@ -95,6 +109,15 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
                    cfg.temb_dim, rows_p=tot),
               _vec("time_emb_proj_all.bias", [(f"{n}.time_emb_proj.bias", ci, o, 0) for n, (o, cp, ci) in lay.items()],
                    rows_p=tot)]
+
+    # every cross-attention K/V projection as row blocks of one weight: one GEMM forward and one weight gradient per step
+    klay, ktot = kv_layout(blocks)
+    if ktot:
+        srcs = []
+        for n, (o, d2) in klay.items():
+            t = n + ".transformer_blocks.0"
+            srcs += [(f"{t}.attn2.to_k.weight", d2, o, 0), (f"{t}.attn2.to_v.weight", d2, o + d2, 0)]
+        E += [_lin("attn2_kv_all", srcs, cfg.cross_attention_dim, rows_p=ktot)]
 
     def res_entries(r):
         if r.dropped:
@@ -127,8 +150,6 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
                 _lin(f"{t}.attn1.to_out.0", [(f"{t}.attn1.to_out.0.weight", c)], d1),
                 _vec(f"{t}.attn1.to_out.0.bias", [(f"{t}.attn1.to_out.0.bias", c)]),
                 _lin(f"{t}.attn2.to_q", [(f"{t}.attn2.to_q.weight", d2)], c),
-                _lin(f"{t}.attn2.to_kv", [(f"{t}.attn2.to_k.weight", d2), (f"{t}.attn2.to_v.weight", d2)],
-                     cfg.cross_attention_dim),
                 _lin(f"{t}.attn2.to_out.0", [(f"{t}.attn2.to_out.0.weight", c)], d2),
                 _vec(f"{t}.attn2.to_out.0.bias", [(f"{t}.attn2.to_out.0.bias", c)]),
                 _lin(f"{t}.ff.net.0.proj", _geglu_rows(f"{t}.ff.net.0.proj.weight", ff), c, rows_p=2 * padc(ff)),
