@@ -449,7 +449,35 @@ def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
         close(y, ref.permute(0, 2, 3, 1).reshape(-1, Co), 2e-2, f"conv mode {mode}")
 
 
-@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cand", [6, 7])
+def test_halo_conv_wgrad(dev, force_cfg, cand):
+    """conv_wgrad_halo_kernel (dY tile + input patch staged once per 128-pixel block, nine taps out of the patch) vs
+    autograd: row-group blocks (64^2, 32^2, 16^2, odd batches), the 8^2 fall-back, channel / output-row tails, one split (overwrite and accumulate) and several (atomics)."""
+    from pdm import _pdmk as k
+    force_cfg("PDMK_WGRAD_CFG", cand)
+    torch.manual_seed(12)
+    dt = torch.bfloat16
+    for Bn, Hs, Ci, Co, sk, acc in ((2, 64, 96, 160, 4, True), (3, 16, 64, 96, 1, False), (1, 32, 160, 64, 1, True),
+                                    (2, 16, 32, 320, 2, True), (5, 16, 352, 96, 3, True), (1, 64, 32, 32, 7, True),
+                                    (3, 8, 64, 96, 2, True)):
+        x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+        w = torch.zeros(Co, Ci, 3, 3, device=dev, requires_grad=True)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1)
+        dy = rnd((Bn, Hs, Hs, Co), dev, dt)
+        (gw,) = torch.autograd.grad(y, w, dy.float().permute(0, 3, 1, 2))
+        P = Bn * Hs * Hs
+        base = 1.0 if (acc or sk > 1) else 0.0
+        dW = torch.full((Co, 9 * Ci), 1.0, device=dev)
+        db = torch.ones(Co, device=dev)
+        k.gemm(dy, x, dW, Co, 9 * Ci, P, Co, 0, 9 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=sk,
+               accumulate=acc, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci), colsum_out=db)
+        used = k.candidate_name(k.A_COLK, k.B_COLK_CONV, k.last_candidate()).startswith("pdmk_ring::conv_wgrad_halo_kernel")
+        assert used == (Hs >= 16), f"{Hs}x{Hs}: halo wgrad eligibility"      # 8x8 images (two per block) exceed the patch buffer
+        close(dW, base + conv_w_pack(gw), 2e-2, f"halo wgrad B{Bn} {Hs}x{Hs} {Ci}->{Co} sk{sk}")
+        close(db, 1.0 + dy.float().sum(dim=(0, 1, 2)), 2e-2, "fused conv bias gradient")
+
+
+@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_ring_wgrad_candidates(dev, force_cfg, cand):
     from pdm import _pdmk as k
     force_cfg("PDMK_WGRAD_CFG", cand)

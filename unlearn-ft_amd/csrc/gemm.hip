@@ -835,4 +835,4 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 104; }
+extern "C" int pdmk_version(void) { return 105; }

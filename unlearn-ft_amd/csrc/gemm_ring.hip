@@ -798,13 +798,236 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
+namespace pdmk_ring {
+
+// ------------------------------------------------------------------------------------------------------------------
+// Halo weight gradient of a stride-1 3x3 conv:  dW[co][tap][ci] (+)= sum_px dY[px][co] * X[src(px, tap)][ci].
+// The ring kernel above gathers X once per tap (9 x the image through L2 -> LDS for one pass over dY).  Here a workgroup
+// owns dW[64 co][9 taps][64 ci] and walks 128-pixel blocks (whole image rows, or whole small images): per block the dY
+// tile [128 px][64 / 128 co] and the (rows+2) x (W+2) input patch [<= 288 px][64 ci] are LDS-DMA-ed ONCE and all nine taps
+// read the patch at shifted rows with transposing ds_read_b64_tr_b16 (patch swizzle chunk ^= row & 7: conflict-free
+// for every shift, as in conv_halo_kernel / the attention tiles).  49 KiB of intake per 9.4 MFLOP (192 FLOP/B) against
+// 32 KiB per 2.1 MFLOP (65 FLOP/B) for the 128x128 ring tile.  8 waves = 2 (co halves) x 4 (16-channel ci slices);
+// a wave keeps 2 x 9 accumulator tiles (72 VGPRs).  Pixel blocks are split over gridDim.y; partial tiles are combined
+// with fp32 atomics in 256-byte rows (plain stores / read-add-store when there is a single split).
+template <int IMW, int STAGES>      // IMW = 16-row co tiles per wave: 2 (64 co per workgroup) or 4 (128 co)
+__global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    typedef Mma<bf16> MM;
+    constexpr int PX = 128, PMAX = 288, BM = 32 * IMW, RA = BM * 2;       // RA = bytes per pixel row of the dY tile
+    constexpr int A_BYTES = PX * RA, P_BYTES = PMAX * 128, SLOT = A_BYTES + P_BYTES;
+    constexpr int PA = A_BYTES / 1024 / 8;                            // dY pieces per wave and stage
+    constexpr int NPW = (PMAX / 8 + 7) / 8;                           // patch pieces per wave and stage (constant count)
+    constexpr int NDMA = PA + NPW;                                    // DMA instructions per wave and stage
+    static_assert(STAGES >= 2 && STAGES * SLOT <= 160 * 1024, "LDS");
+    static_assert((IMW == 2 || IMW == 4) && BM * 68 * 4 <= STAGES * SLOT, "epilogue staging");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int Ci = g.conv_ci, H = g.conv_hi, W = g.conv_wi, HW = H * W;
+    const int nct = (Ci + 63) / 64;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / nct) * BM, c0 = (tile - (tile / nct) * nct) * 64;
+    const int nblk = (g.K + PX - 1) / PX;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int kb0 = blockIdx.y * per, kb1 = min(nblk, kb0 + per);
+    if (kb0 >= kb1) return;
+
+    const int rimg = HW >= PX ? PX / W : H;                           // rows of an image inside a pixel block
+    // patch row stride padded to a multiple of 8 pixels: (row + ky * W2) & 7 == row & 7, so the swizzle term of a tap
+    // address does not depend on ky and the three ky reads of a kx share one address computation
+    const int W2 = (W + 2 + 7) & ~7, pimg = (rimg + 2) * W2;
+    const int nimg = HW >= PX ? 1 : PX / HW;
+    const int prows = nimg * pimg;
+
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), (short)0, (int)a_bytes, 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.B), (short)0, (int)b_bytes, 0x00020000);
+
+    // ---- dY loader (as wgrad_ring): 128-byte rows: piece = 8 pixel rows, lane -> (row lane>>3, chunk lane&7);
+    //      256-byte rows: piece = 4 pixel rows, lane -> (row lane>>4, chunk lane&15); swizzles 2 f128(k) / 2 f256(k)
+    const int a_row = RA == 256 ? (lane >> 4) : (lane >> 3);
+    const int a_lc = RA == 256 ? ((lane & 15) ^ (((lane >> 4) | (((wave >> 1) & 1) << 2)) << 1))
+                               : ((lane & 7) ^ (((((lane >> 3) >> 1) & 1) | ((wave & 1) << 1)) << 1));
+    const int acol = m0 + a_lc * 8;
+    const bool a_ok = acol < g.M;
+    // ---- patch loader: piece = j*8 + wave, lane -> (row sr, physical chunk lane&7); logical chunk ^= row & 7
+    const int sr = lane >> 3;
+    const int pch = c0 + (((lane & 7) ^ sr) << 3);                    // first channel of this lane's chunk
+    const bool p_ok = pch < Ci;
+    int p_il[NPW], p_dy[NPW], p_dx[NPW];                              // patch row -> (image in block, y - y0, x); il < 0: none
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        const int prow = (j * 8 + wave) * 8 + sr;
+        p_il[j] = -1;
+        p_dy[j] = p_dx[j] = 0;
+        if (prow < prows) {
+            const int il = prow / pimg, rem = prow - il * pimg;
+            const int py = rem / W2;
+            p_il[j] = il;
+            p_dy[j] = py - 1;
+            p_dx[j] = rem - py * W2 - 1;
+        }
+    }
+
+    auto issue = [&](int kb, int slot) {
+        unsigned char* sa = smem + slot * SLOT;
+        const int p0 = kb * PX;
+        const int img0 = p0 / HW, y0 = (p0 - img0 * HW) / W;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int piece = i * 8 + wave;
+            const int px = p0 + piece * (1024 / RA) + a_row;
+            const unsigned va = (px < g.K && a_ok) ? ((unsigned)px * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + piece * 1024), 16, (int)va, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NPW; ++j) {
+            // surplus pieces (beyond the patch) re-issue piece j = 0 of this wave: identical bytes, constant DMA count
+            const bool real = (j * 8 + wave) * 8 < prows;
+            const int jj = real ? j : 0;
+            const int il = real ? p_il[j] : p_il[0], dy = real ? p_dy[j] : p_dy[0], dx = real ? p_dx[j] : p_dx[0];
+            unsigned vb = OOB;
+            const int b = img0 + il, y = y0 + dy;
+            if (il >= 0 && p_ok && b < g.conv_b && (unsigned)y < (unsigned)H && (unsigned)dx < (unsigned)W)
+                vb = ((unsigned)((b * H + y) * W + dx) * (unsigned)g.conv_ld + (unsigned)pch) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sa + A_BYTES + (jj * 8 + wave) * 1024), 16, (int)vb, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[IMW][9], acs[IMW];
+#pragma unroll
+    for (int i = 0; i < IMW; ++i) {
+        acs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_colsum = g.colsum_out != nullptr && c0 == 0 && wn == 0;      // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    // ---- transposing fragment reads: lane (tg, tq, tp) reads 8 bytes of k-row kk + 8 tg + tq (and of row + 4)
+    const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int fsw = RA == 256 ? ((tq | ((tg & 1) << 2)) << 1) : ((((tq >> 1) & 1) | ((tg & 1) << 1)) << 1);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto tr_a = [&](const unsigned char* base, int kk, int col0) -> bf16x8 {
+        const unsigned ch = (unsigned)(((col0 >> 3) ^ fsw) | (tp >> 1));
+        const unsigned char* a0 = base + (unsigned)(kk + 8 * tg + tq) * (unsigned)RA + ch * 16u + (unsigned)(tp & 1) * 8u;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * RA));
+        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // patch row of pixel k of a block for tap (0,0): k -> (image il, row yl, column x)
+    int prk[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = c * 32 + 8 * tg + tq + 4 * h;
+            const int il = k / (rimg * W), rem = k - il * (rimg * W);
+            const int yl = rem / W;
+            prk[c][h] = il * pimg + yl * W2 + (rem - yl * W);
+        }
+    const unsigned bch = (unsigned)(2 * wn + (tp >> 1)), bsub = (unsigned)(tp & 1) * 8u;
+    const int rowb = W2 * 128;                                       // bytes between patch rows ky and ky + 1
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (kb0 + s < kb1) issue(kb0 + s, s);
+
+    int slot = 0;
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int ahead = min(STAGES - 2, kb1 - 1 - kb);
+        wait_vmcnt_dyn(ahead * NDMA);
+        __builtin_amdgcn_s_barrier();
+        if (kb + STAGES - 1 < kb1) issue(kb + STAGES - 1, slot == 0 ? STAGES - 1 : slot - 1);
+        const unsigned char* sa = smem + slot * SLOT;
+        const unsigned char* pb = sa + A_BYTES;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bf16x8 af[IMW];
+#pragma unroll
+            for (int i = 0; i < IMW; ++i) af[i] = tr_a(sa, c * 32, wm * (16 * IMW) + i * 16);
+            asm volatile("" : "+v"(prk[c][0]), "+v"(prk[c][1]));     // keep the shifted addresses out of the loop invariants
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const int r0 = prk[c][0] + tx, r1 = prk[c][1] + tx;
+                const unsigned char* q0 = pb + (unsigned)r0 * 128u + ((bch ^ (unsigned)(r0 & 7)) << 4) + bsub;
+                const unsigned char* q1 = pb + (unsigned)r1 * 128u + ((bch ^ (unsigned)(r1 & 7)) << 4) + bsub;
+#pragma unroll
+                for (int ty = 0; ty < 3; ++ty) {
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + ty * rowb));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q1 + ty * rowb));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int i = 0; i < IMW; ++i) acc[i][ty * 3 + tx] = MM::mma(bf, af[i], acc[i][ty * 3 + tx]);
+                }
+            }
+            if (do_colsum) {
+#pragma unroll
+                for (int i = 0; i < IMW; ++i) acs[i] = MM::mma(ones, af[i], acs[i]);
+            }
+        }
+        slot = slot + 1 == STAGES ? 0 : slot + 1;
+    }
+    if (do_colsum && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < IMW; ++i) {
+            const int m = m0 + wm * (16 * IMW) + i * 16 + (lane & 15);
+            if (m < g.M) unsafeAtomicAdd(g.colsum_out + m, acs[i][0]);
+        }
+    }
+    // ---- epilogue: one tap at a time through a [BM][68] fp32 staging image; a wave writes BM/8 rows of 64 floats
+    constexpr int SROW = 68;
+    float* stage = reinterpret_cast<float*>(smem);
+    float* Cf = reinterpret_cast<float*>(g.C);
+    const bool atomic = gridDim.y > 1, acc1 = g.accumulate == 1;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IMW; ++i)
+            *reinterpret_cast<f32x4*>(stage + (wm * (16 * IMW) + i * 16 + (lane & 15)) * SROW + wn * 16 + (lane >> 4) * 4) = acc[i][t];
+        __syncthreads();
+        const int ci = c0 + lane;
+        if (ci < Ci) {
+#pragma unroll
+            for (int rr = 0; rr < BM / 8; ++rr) {
+                const int row = wave * (BM / 8) + rr, m = m0 + row;
+                if (m < g.M) {
+                    const float v = stage[row * SROW + lane];
+                    float* dst = Cf + (long)m * g.ldc + t * Ci + ci;
+                    if (atomic) unsafeAtomicAdd(dst, v);
+                    else *dst = acc1 ? *dst + v : v;
+                }
+            }
+        }
+    }
+}
+
+static bool wgrad_halo_ok(const pdmk_gemm_args& g) {
+    if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode != PDMK_B_COLK_CONV || !g.out_f32) return false;
+    if (g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi || g.accumulate == 2 || g.alpha != 1.0f) return false;
+    if ((g.conv_ci % 8) || (g.conv_ld % 8) || (g.lda % 8) || (g.M % 8) || g.N != 9 * g.conv_ci || g.conv_wi < 4) return false;
+    const int H = g.conv_hi, W = g.conv_wi, HW = H * W, W2 = (W + 2 + 7) & ~7;
+    if (HW >= 128) return (HW % 128) == 0 && (128 % W) == 0 && (128 / W + 2) * W2 <= 288;
+    return (128 % HW) == 0 && (128 / HW) * (H + 2) * W2 <= 288;
+}
+
+}  // namespace pdmk_ring
+
 // ---- weight-gradient ring candidates: 128x128 deep / shallow rings, and the smaller tiles whose split-K epilogue moves a
 // quarter to a half of the atomic bytes per workgroup (what bounds the small weights: ~5 GB/s of atomics per CU)
 struct WCfg { int bm, nj, stages, occ; };
 static const WCfg kWCfgs[] = {{128, 4, 4, 2}, {128, 4, 2, 4}, {64, 4, 3, 4}, {128, 2, 3, 4}, {64, 2, 4, 4}};
 constexpr int kNumW = sizeof(kWCfgs) / sizeof(kWCfgs[0]);
-int pdmk_wgrad_ring_num_configs() { return kNumW; }
+int pdmk_wgrad_ring_num_configs() { return kNumW + 2; }      // + the halo conv weight gradients (64 / 128 output rows)
 int pdmk_wgrad_ring_name(int id, int conv, char* buf, int n) {
+    if (id == kNumW || id == kNumW + 1) {
+        snprintf(buf, n, "pdmk_ring::conv_wgrad_halo_kernel<%d, %d>", id == kNumW ? 2 : 4, id == kNumW ? 3 : 2);
+        return 0;
+    }
     if (id < 0 || id >= kNumW) return -1;
     const WCfg c = kWCfgs[id];
     snprintf(buf, n, "pdmk_ring::wgrad_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
@@ -816,6 +1039,15 @@ int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes
     const bool conv = g.b_mode == PDMK_B_COLK_CONV;
     if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
     if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3)) return 1;
+    if (id == kNumW || id == kNumW + 1) {
+        if (!wgrad_halo_ok(g)) return 1;
+        const int nblk = (g.K + 127) / 128, sk = g.splitk > 1 ? g.splitk : 1, bm = id == kNumW ? 64 : 128;
+        if (sk > nblk) return 1;
+        dim3 grid(((g.M + bm - 1) / bm) * ((g.conv_ci + 63) / 64), sk);
+        if (bm == 64) hipLaunchKernelGGL((conv_wgrad_halo_kernel<2, 3>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
+        else hipLaunchKernelGGL((conv_wgrad_halo_kernel<4, 2>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     if (id < 0 || id >= kNumW) return 1;
     int lg_wo = -1, lg_howo = -1;
     if (conv) {
