@@ -88,3 +88,23 @@ def test_cli_flags_of_reference_slurm_scripts_parse():
     a = parse_args(["--base_config_path", "x.yaml", "--cache_dir", "/c", "--wandb_run_name", "r", "--pruning_ckpt_dir",
                     "/p", "--expert_id", "5"])
     assert a.expert_id == 5 and a.seed == 43 and a.pretrained_model_name_or_path == "stabilityai/stable-diffusion-2-1"
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_bench.json is a verbatim bench.py line: every field of the measurement contract must be present."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "images/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "two_sided"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port")
+    assert abs(d["value"] - d["steps"] * d["config"]["global_batch"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.05 * d["value"]
