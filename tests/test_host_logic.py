@@ -108,3 +108,14 @@ def test_committed_bench_line_has_the_contract_fields():
         assert key in c, key
     assert c["kind"] in ("reference", "port")
     assert abs(d["value"] - d["steps"] * d["config"]["global_batch"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 0.05 * d["value"]
+
+
+def test_empty_batch_rule_follows_the_reference():
+    """trainer.py:2771-2772 skips a batch when `pixel_values.numel() == 0` (collate_fn's all-samples-failed case)."""
+    import torch
+    from pdm.training.trainer import Trainer
+    z = torch.zeros(0)
+    assert Trainer._is_empty({"pixel_values": z, "prompt_embeds": torch.zeros(2, 77, 1024)})
+    assert not Trainer._is_empty({"pixel_values": torch.zeros(1, 3, 8, 8), "prompt_embeds": z})
+    assert Trainer._is_empty({"latents": z}) and not Trainer._is_empty({"latents": torch.zeros(1, 4, 8, 8)})
+    assert Trainer._is_empty({"input_ids": torch.zeros(0, 77, dtype=torch.int64)}) and Trainer._is_empty({})

@@ -115,6 +115,15 @@ class Trainer:
             self._empty_cache = {}
         return self._text_encoder
 
+    @staticmethod
+    def _is_empty(batch):
+        """collate_fn yields zero-element tensors when every sample of a batch failed to load (data_utils.py:286-312);
+        the reference tests `pixel_values.numel() == 0`."""
+        for key in ("pixel_values", "latents", "prompt_embeds", "input_ids"):
+            if key in batch:
+                return batch[key].numel() == 0
+        return True
+
     def _prompt_embeds(self, batch, empty=False):
         """`prompt_embeds` / `empty_prompt_embeds` as given, else encoded from `input_ids` / `empty_input_ids`."""
         key, ids_key = ("empty_prompt_embeds", "empty_input_ids") if empty else ("prompt_embeds", "input_ids")
@@ -302,7 +311,7 @@ class UnetFineTuner(Trainer):
         for batch in self.train_dataloader:
             if self.global_step >= max_steps:
                 break
-            if batch.get("prompt_embeds", batch.get("input_ids")).numel() == 0:   # empty batch is skipped (trainer.py:2771-2772)
+            if self._is_empty(batch):                        # empty batch is skipped (trainer.py:2771-2772)
                 continue
             loss = self.step(batch)
             lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
