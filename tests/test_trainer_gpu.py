@@ -158,3 +158,25 @@ def test_local_snapshot_and_pruning_checkpoint_flow_in(dev, tmp_path):
     assert torch.equal(re.arch_vector, tr.arch_vector)
     a, b = tr.prediction_model.state_dict(), re.state_dict()
     assert set(a) == set(b) and all(torch.equal(a[n], b[n]) for n in a)
+
+
+def test_image_logging_samples_with_the_current_student(dev, tmp_path):
+    """trainer.py:2543-2575 / :2851-2859: every `image_logging_steps` the prompt batches are sampled with the student
+    (PNDM + guidance + VAE decode) - written as uint8 arrays here instead of a wandb grid; seeded, so repeatable."""
+    import numpy as np
+    from pdm.training.trainer import UnetFineTuner
+    cfg = _config(tmp_path, 2)
+    cfg["training"]["image_logging_steps"] = 1
+    cfg["training"]["num_inference_steps"] = 3
+    ids = torch.randint(0, 1000, (2, 13), generator=torch.Generator().manual_seed(0))
+    prompts = [{"input_ids": ids, "empty_input_ids": torch.zeros(2, 13, dtype=torch.int64)}]
+    tr = UnetFineTuner(cfg, prompt_dataloader=prompts)
+    tr.train()
+    files = sorted(os.listdir(tmp_path / "images"))
+    assert files == ["step-0.npy", "step-1.npy"]
+    a, b = np.load(tmp_path / "images" / files[0]), np.load(tmp_path / "images" / files[1])
+    assert a.shape == (2, 64, 64, 3) and a.dtype == np.uint8 and a.std() > 0
+    assert not np.array_equal(a, b)                       # the student moved between the two logging points
+    again = tr.generate_samples_from_prompts()            # same weights + same seed -> same images
+    assert np.array_equal((again.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy(),
+                          (tr.generate_samples_from_prompts().permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy())

@@ -64,8 +64,9 @@ class SyntheticBatches:
 class Trainer:
     bilevel = False
 
-    def __init__(self, config, train_dataloader=None, upper_dataloader=None):
+    def __init__(self, config, train_dataloader=None, upper_dataloader=None, prompt_dataloader=None):
         self.config = config
+        self.prompt_dataloader = prompt_dataloader     # batches of {"input_ids" | "prompt_embeds", "empty_input_ids" | ...}
         self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         local = int(os.environ.get("LOCAL_RANK", 0))
@@ -252,6 +253,41 @@ class Trainer:
         tot = (w["up_dist"] * s + w["up_block"] * b) if upper else (w["diff"] * d + w["block"] * b + w["dist"] * s)
         return tot.float(), (torch.zeros_like(d) if upper else d).float(), s.float(), b.float()
 
+    # ---- image logging (trainer.py:2543-2575 generate_samples_from_prompts; called every image_logging_steps, :2851-2859)
+    def get_pipeline(self):
+        from ..pipelines.pruning_pipelines import PNDMScheduler, StableDiffusionPruningPipeline
+        pt = _cfg(self.config, "model.prediction_model.prediction_type", "v_prediction")
+        return StableDiffusionPruningPipeline(self.vae, self.text_encoder, self.prediction_model,
+                                              PNDMScheduler(prediction_type=pt))
+
+    def generate_samples_from_prompts(self):
+        """Samples every prompt batch with the current student (PNDM, `training.num_inference_steps`, guidance 7.5, the
+        configured seed) and writes `<logging_dir>/images/step-<n>.npy` ([N, H, W, 3] uint8) instead of a wandb image grid."""
+        if self.prompt_dataloader is None:
+            return None
+        pipe = self.get_pipeline()
+        steps = int(_cfg(self.config, "training.num_inference_steps", 50))
+        seed = _cfg(self.config, "seed", None)
+        res = int(_cfg(self.config, "model.prediction_model.resolution", 512)) // 8 * self.vae_factor
+        images = []
+        for batch in self.prompt_dataloader:
+            gen = None if seed is None else torch.Generator(device=self.device).manual_seed(int(seed))
+            kw = {}
+            for src, dst in (("prompt_embeds", "prompt_embeds"), ("empty_prompt_embeds", "negative_prompt_embeds"),
+                             ("input_ids", "prompt_ids"), ("empty_input_ids", "negative_prompt_ids")):
+                if src in batch:
+                    kw[dst] = batch[src]
+            images.append(pipe.generate_samples(num_inference_steps=steps, generator=gen, output_type="pt", height=res,
+                                                width=res, **kw).images)
+        images = torch.cat(images)
+        if self.rank == 0:
+            d = os.path.join(self.logging_dir, "images")
+            os.makedirs(d, exist_ok=True)
+            import numpy as np
+            np.save(os.path.join(d, f"step-{self.global_step}.npy"),
+                    (images.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy())
+        return images
+
     # ---- checkpointing (trainer.py:452-514, 2863-2869)
     def save_checkpoint(self):
         if self.rank != 0:
@@ -335,6 +371,9 @@ class UnetFineTuner(Trainer):
                 self._flush(*pending)
             pending = (rec, keys, host, torch.cuda.Event())
             pending[3].record()
+            log_every = int(_cfg(c, "training.image_logging_steps", 0) or 0)
+            if log_every and self.prompt_dataloader is not None and self.global_step % log_every == 0:
+                self.generate_samples_from_prompts()
             self.global_step += 1
             if self.global_step % ck_every == 0:
                 self.save_checkpoint()
