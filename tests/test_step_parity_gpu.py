@@ -325,3 +325,45 @@ def test_bilevel_loss_curve_matches_oracle_fp32(dev):
     new = student.state_dict()
     drift = max((new[n] - psd[n]).abs().max().item() for n in psd)
     assert drift > 5e-5
+
+
+def test_deferred_wt_refresh_is_complete_before_backward(dev):
+    """The transposed (dgrad) weight copies are refreshed on a side stream at the start of the NEXT training step, not by
+    the optimiser: after an optimiser step they are stale, and by the end of the next step they equal a fresh transpose of
+    the updated weights (the backward waited for the side stream)."""
+    from pdm.training.bilevel import BilevelStepper
+    ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16)
+    lat, noise, t, ehs, empty = _inputs()
+    store = student.store
+    st = BilevelStepper(student, teacher, lr=1e-2, upper_lr=1e-2, bilevel=True)
+    assert store.defer_wt
+    st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+    st.optimizer_step()
+    torch.cuda.synchronize()
+    stale = store.wt.clone()
+    for step_fn in (lambda: st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda()),
+                    lambda: st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda())):
+        step_fn()
+        torch.cuda.synchronize()
+        got = store.wt.clone()
+        store.refresh_wt()
+        torch.cuda.synchronize()
+        assert torch.equal(got, store.wt)
+        st.optimizer_step(upper=False)
+        torch.cuda.synchronize()
+    assert not torch.equal(stale, store.wt)
+    # and the gradients of a deferred step equal those of a step whose copies were refreshed with the optimiser
+    g_def = store.grad.clone()
+    store.defer_wt = False
+    store.refresh_wt()
+    k_ = __import__("pdm._pdmk", fromlist=["x"])
+    k_.zero_(store.grad)
+    st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+    torch.cuda.synchronize()
+    g_now = store.grad.clone()
+    store.defer_wt = True
+    k_.zero_(store.grad)
+    st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+    torch.cuda.synchronize()
+    assert torch.allclose(store.grad, g_now, rtol=0, atol=1e-6 * float(g_now.abs().max()) + 1e-12) or \
+        torch.nn.functional.cosine_similarity(store.grad, g_now, dim=0).item() > 0.99999

@@ -194,6 +194,7 @@ class ParamStore:
         self.grad = torch.zeros(self.total, device=device, dtype=torch.float32) if train else None
         self.w = self.master if dtype == torch.float32 else torch.zeros(self.total, device=device, dtype=dtype)
         self.wt = torch.zeros(self.total, device=device, dtype=dtype) if train else None
+        self.defer_wt = False          # set by the stepper: optimiser steps skip the wt refresh, training steps begin with it
 
     # ---- views
     def _v(self, arena, key):
@@ -251,10 +252,16 @@ class ParamStore:
         tab = np.where(tab >= 2 ** 31, tab - 2 ** 32, tab).astype(np.int32)
         return torch.from_numpy(tab).to(self.master.device), tab.shape[0]
 
-    def refresh(self, w_is_fresh=False):
-        """master -> w (cast) -> wt (tiled transposes), two launches.  `w_is_fresh`: the fused AdamW already wrote w."""
+    def refresh(self, w_is_fresh=False, wt=True):
+        """master -> w (cast) -> wt (tiled transposes), two launches.  `w_is_fresh`: the fused AdamW already wrote w.
+        `wt=False` leaves the transposed (dgrad) copies to a later `refresh_wt()` - they are not read before the next
+        backward pass, so the stepper launches that pass beside the next forward instead of after the optimiser."""
         if self.dtype != torch.float32 and not w_is_fresh:
             k.cast_permute(self.master, self.w, self.total, 1, 1, 0)
+        if wt:
+            self.refresh_wt()
+
+    def refresh_wt(self):
         if self.wt is not None:
             if not hasattr(self, "_tiles"):
                 self._tiles = self._tile_table()

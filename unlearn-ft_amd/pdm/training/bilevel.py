@@ -59,7 +59,7 @@ class FusedAdamW:
         fused = s.dtype == torch.bfloat16
         k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
                 self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
-        s.refresh(w_is_fresh=fused)
+        s.refresh(w_is_fresh=fused, wt=not s.defer_wt)
 
     def launch_range(self, lo, hi, grad_scale=1.0, zero_grad=True):
         """AdamW on arena slice [lo, hi) only (no refresh of the transposed copies): lets the update of layers whose
@@ -165,6 +165,11 @@ class BilevelStepper:
         self.teacher_stream = (torch.cuda.Stream(device=self.dev) if os.environ.get("PDMK_TEACHER_STREAM", "1") != "0"
                                else None)
         self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # 32 bytes: zeroed by k.zero_   # diff, dist, block, (unused)
+        # transposed (dgrad) weight copies are refreshed at the START of the next training step, beside its forward, instead
+        # of at the end of the optimiser step (PDMK_DEFER_WT=0: refresh with the optimiser as before)
+        self.wt_stream = torch.cuda.Stream(device=self.dev)
+        self._wt_pending = False
+        student.store.defer_wt = os.environ.get("PDMK_DEFER_WT", "1") != "0"
 
     # ------------------------------------------------------------------ pieces
     def _diffuse(self, latents, noise, timesteps, want_target):
@@ -193,7 +198,22 @@ class BilevelStepper:
                 a.g = torch.empty_like(a.t)
                 k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
 
+    def _begin_wt_refresh(self):
+        """The dgrad copies `wt` (W^T, flipped conv taps) of the weights the last optimiser step wrote are only read by the
+        backward pass: their refresh (one 3.4 GB HBM-bound pass) runs on a side stream beside the forward."""
+        store = self.student.store
+        if not store.defer_wt:
+            return
+        cur = torch.cuda.current_stream()
+        self.wt_stream.wait_stream(cur)
+        with torch.cuda.stream(self.wt_stream):
+            store.refresh_wt()
+        self._wt_pending = True
+
     def _backward_and_reduce(self):
+        if self._wt_pending:
+            torch.cuda.current_stream().wait_stream(self.wt_stream)
+            self._wt_pending = False
         if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between captured graphs
             self.student.engine.grad_ready_cb = self.segment_cb      # None, or GraphedBilevel's capture-segment switch
             self.student.engine.backward()
@@ -214,6 +234,8 @@ class BilevelStepper:
         B, C, H, W = latents.shape
         w = self.w
         need_teacher = w["block"] > 0 or w["dist"] > 0
+        if backward:
+            self._begin_wt_refresh()
         noisy, target = self._diffuse(latents, noise, timesteps, True)
         ehs = self._ehs2d(prompt_embeds)
         k.zero_(self.losses)
@@ -248,6 +270,8 @@ class BilevelStepper:
         predictions computed as ONE batch of 2B."""
         B, C, H, W = latents.shape
         w = self.w
+        if backward:
+            self._begin_wt_refresh()
         noisy, _ = self._diffuse(latents, noise, timesteps, False)
         ehs = self._ehs2d(prompt_embeds)
         ehs2 = torch.cat([ehs, self._ehs2d(empty_prompt_embeds)], 0)
@@ -425,7 +449,7 @@ class GraphedBilevel:
                 if self.stream_opt and not multi:
                     fork_adamw(0)
                     torch.cuda.current_stream().wait_stream(self.opt_stream)
-                    store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
+                    store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
                 graphs[-1].capture_end()
         finally:
             if gc_was_on:
@@ -444,7 +468,7 @@ class GraphedBilevel:
                 g.replay()
             if opt is not None and self.stream_opt and len(graphs) > 1:      # forced segments on one rank (tests)
                 opt.launch_range(0, store.total, st._gscale)
-                store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
+                store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
             return
         red = st.reducer
         red.begin()
@@ -459,7 +483,7 @@ class GraphedBilevel:
         red.finish()
         if opt is not None and self.stream_opt:
             opt.launch_range(0, done, st._gscale)
-            store.refresh(w_is_fresh=store.dtype == torch.bfloat16)
+            store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
 
     def main(self, lat, noise, t, ehs):
         lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches inside the step
