@@ -64,6 +64,13 @@ def test_conv_mode4_rejects_odd_sides_and_wgrad(dev):
     C = torch.zeros(2 * 3, 32, device=dev, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError):
         k.gemm(x, w, C, 6, 32, 288, 0, 288, 32, a_mode=k.A_CONV, conv=(1, 5, 6, 32, 3, 3, 4, 32))
+    # forward only: the encoder is frozen, a mode-4 weight gradient is refused rather than silently computed as mode 1
+    x2 = torch.zeros(1, 8, 8, 32, device=dev, dtype=torch.bfloat16)
+    dy = torch.zeros(16, 32, device=dev, dtype=torch.bfloat16)
+    dW = torch.zeros(32, 288, device=dev)
+    with pytest.raises(RuntimeError):
+        k.gemm(dy, x2, dW, 32, 288, 16, 32, 0, 288, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True,
+               conv=(1, 8, 8, 32, 4, 4, 4, 32))
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
