@@ -5,7 +5,12 @@
  * (SURVEY.md 2.3, 8b).  Each entry point below names the reference call site(s) whose arithmetic it replaces.
  *
  * Conventions
- *  - every pointer is a DEVICE pointer owned by the caller; the library allocates nothing and keeps no state;
+ *  - every pointer is a DEVICE pointer owned by the caller, workspaces included: the *_workspace_bytes() queries below
+ *    size them.  The library keeps no state and allocates nothing - with ONE documented exception, the GEMM plan cache
+ *    (see "Plan cache" below): a process-global, mutex-guarded map from GEMM shape to the fastest candidate kernel,
+ *    filled by timing the candidates on the device the first time a shape is seen outside stream capture, into a
+ *    hipMalloc-ed scratch output owned by the library (device current at that time; freed by pdmk_plan_clear).
+ *    PDMK_GEMM_TUNE=0 turns the exception off: pdmk_gemm is then a pure function of its arguments (static heuristics);
  *  - activations are NHWC / token-major: a [B, H*W, C] matrix with an explicit row stride ("ld", in elements);
  *  - dtype: PDMK_F32 (exact fp32 MFMA / fp32 storage, parity runs) or PDMK_BF16 (bf16 storage + MFMA, fp32
  *    accumulation and statistics).  Parameters that stay fp32 in both modes (bias, norm affine, statistics, loss
@@ -101,6 +106,18 @@ int pdmk_gemm_candidate_name(int a_mode, int b_mode, int id, char* buf, int n);
 int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
                        int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int nslab /* slabs in ws */,
                        int accumulate, int dtype, pdmk_stream stream);
+/* Bytes of the fp32 slab workspace of a split-K forward / dgrad GEMM ([splitk][M][N]); -1 on bad arguments. */
+int64_t pdmk_gemm_splitk_workspace_bytes(int64_t M, int N, int splitk);
+
+/* Plan cache (the library's only state).  pdmk_plan_export writes every cached (shape -> candidate / split-K) decision to
+ * a text file, pdmk_plan_import merges such a file (returns the number of entries read, -2 if it was written by a build
+ * with another candidate numbering), pdmk_plan_size counts the entries, pdmk_plan_clear drops them and frees the tuning
+ * scratch.  Data-parallel jobs export rank 0's plans after its warm-up and import them on the other ranks, so that every
+ * rank launches the same kernels (same split-K sums, no rank-to-rank timing skew). */
+int pdmk_plan_export(const char* path);
+int pdmk_plan_import(const char* path);
+int pdmk_plan_size(void);
+int pdmk_plan_clear(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC.  Replaces F.group_norm + F.silu at blocks.py:318-319, 348+371,
@@ -118,6 +135,9 @@ int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gam
                        const float* stats, float* dgamma, float* dbeta, double* ws, float* part_ws,
                        int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G, int gs,
                        int silu, int accumulate_dx, int dtype, pdmk_stream stream);
+/* Bytes of `ws` (forward and backward) and of `part_ws` (backward). */
+int64_t pdmk_groupnorm_workspace_bytes(int B, int G);
+int64_t pdmk_groupnorm_bwd_part_workspace_bytes(int G, int gs);
 
 /* LayerNorm over the last dim (eps 1e-5; diffusers BasicTransformerBlock.norm1/2/3). stats [M,2]. */
 int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M, int C,
@@ -125,6 +145,7 @@ int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* 
 int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
                        float* dgamma, float* dbeta, float* part_ws, int64_t part_ws_elems /* >= (M/16 + 1) * 2 * C */,
                        int M, int C, int ldx, int lddy, int lddx, int accumulate_dx, int dtype, pdmk_stream stream);
+int64_t pdmk_layernorm_bwd_part_workspace_bytes(int M, int C);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, head dim 64, no mask, no dropout (F.scaled_dot_product_attention at
@@ -144,6 +165,8 @@ int pdmk_attn_bwd(const void* q, const void* k, const void* v, const void* o, co
                   int64_t k_bs, int k_ld, int64_t v_bs, int v_ld, int64_t o_bs, int o_ld, int64_t dq_bs, int dq_ld,
                   int64_t dk_bs, int dk_ld, int64_t dv_bs, int dv_ld, float scale, float* ws, int64_t ws_elems,
                   int dtype, pdmk_stream stream);
+/* Bytes of `ws` worth passing for this shape (0: pass NULL - the key blocks alone fill the chip). */
+int64_t pdmk_attn_bwd_workspace_bytes(int B, int H, int Nq, int Nk);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise / reduction family.

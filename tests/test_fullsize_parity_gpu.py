@@ -1,0 +1,222 @@
+"""Full-size parity (-m gpu): the REAL SD-2.1 topology against the CPU oracle, gradients included.
+
+Round-1 stopped at full-size *losses*; this file closes the remaining BASELINE.json configurations:
+
+  configs[0]/[1]/[2]  MAC-budget-0.55 student, B=1, 64x64 latent: main step AND upper (concept-suppression) step -
+                      losses + parameter gradients (every tensor; a named set spread over down/mid/up is asserted at the
+                      tight tolerance) for the fp32 engine (2e-3 of each tensor's scale) and the bf16 engine (cosine >= 0.98)
+  configs[3]          "82 %-pruned" in its second reading: keep ~ 0.18 of the MACs - main-step losses
+  configs[4]          dense student, 96x96 latents (768^2 images), B=1 - main-step losses (N = 9216 self-attention)
+
+Reference arithmetic: pdm/training/trainer.py:2403-2488 (step), :2904-3001 (upper_step); attention blocks.py:257-277.
+The oracle runs ONCE per (budget, step kind) (module-scoped cache) and both engine dtypes are compared with it.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# gradients asserted at the tight tolerance: conv1/conv2, shortcut, samplers, q/k/v/out of both attentions (the K/V rows
+# are column slices of the engine's ONE batched cross-attention projection), GEGLU + FF out, every norm kind, the
+# time-embedding MLP and time_emb_proj rows (row blocks of the engine's ONE batched projection), first and last conv
+NAMED = [
+    "conv_in.weight", "conv_out.weight", "conv_out.bias", "conv_norm_out.weight", "conv_norm_out.bias",
+    "time_embedding.linear_1.weight", "time_embedding.linear_2.weight", "time_embedding.linear_2.bias",
+    "down_blocks.0.resnets.0.norm1.weight", "down_blocks.0.resnets.0.conv1.weight", "down_blocks.0.resnets.0.conv1.bias",
+    "down_blocks.0.resnets.0.time_emb_proj.weight", "down_blocks.0.resnets.0.norm2.bias",
+    "down_blocks.0.resnets.0.conv2.weight",
+    "down_blocks.0.attentions.0.norm.weight", "down_blocks.0.attentions.0.proj_in.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.norm1.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_k.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_v.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_q.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_v.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_out.0.bias",
+    "down_blocks.0.attentions.0.transformer_blocks.0.norm3.bias",
+    "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.weight",
+    "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.0.proj.bias",
+    "down_blocks.0.attentions.0.transformer_blocks.0.ff.net.2.weight",
+    "down_blocks.0.attentions.0.proj_out.weight",
+    "down_blocks.0.downsamplers.0.conv.weight",
+    "down_blocks.1.resnets.0.conv_shortcut.weight", "down_blocks.1.resnets.0.conv1.weight",
+    "down_blocks.1.attentions.1.transformer_blocks.0.attn1.to_k.weight",
+    "down_blocks.2.resnets.1.conv2.weight", "down_blocks.2.attentions.0.transformer_blocks.0.ff.net.2.weight",
+    "down_blocks.2.attentions.1.transformer_blocks.0.attn2.to_v.weight",
+    "down_blocks.3.resnets.0.conv1.weight", "down_blocks.3.resnets.1.time_emb_proj.weight",
+    "mid_block.resnets.0.conv2.weight", "mid_block.attentions.0.transformer_blocks.0.attn1.to_v.weight",
+    "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "mid_block.resnets.1.norm1.weight",
+    "up_blocks.0.resnets.0.conv1.weight", "up_blocks.0.resnets.2.conv_shortcut.weight", "up_blocks.0.upsamplers.0.conv.weight",
+    "up_blocks.1.resnets.2.conv1.weight", "up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.weight",
+    "up_blocks.1.attentions.0.transformer_blocks.0.ff.net.2.weight", "up_blocks.1.upsamplers.0.conv.weight",
+    "up_blocks.2.resnets.0.conv_shortcut.weight", "up_blocks.2.attentions.1.transformer_blocks.0.attn1.to_q.weight",
+    "up_blocks.2.resnets.2.conv2.weight",
+    "up_blocks.3.resnets.0.time_emb_proj.weight", "up_blocks.3.resnets.2.conv1.weight", "up_blocks.3.resnets.2.norm2.weight",
+    "up_blocks.3.attentions.2.transformer_blocks.0.attn1.to_out.0.weight",
+    "up_blocks.3.attentions.2.transformer_blocks.0.ff.net.0.proj.weight", "up_blocks.3.attentions.2.proj_out.weight",
+]
+
+_CACHE = {}
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def _inputs(hw=64):
+    g = torch.Generator().manual_seed(43)
+    lat, noise = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    t, ehs = torch.tensor([431]), torch.randn(1, 77, 1024, generator=g)
+    empty = torch.randn(1, 77, 1024, generator=g)
+    return lat, noise, t, ehs, empty
+
+
+def _dense(seed=0):
+    """The dense SD-2.1 state dict every model of this module shares (engine random init, fp32 master)."""
+    if ("dense", seed) not in _CACHE:
+        from pdm.models.unet.spec import UNetConfig
+        from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+        m = UNet2DConditionModelPruned(UNetConfig.sd21(), None, "cuda:0", torch.float32, train=False, seed=seed)
+        _CACHE[("dense", seed)] = m.state_dict()
+        del m
+        torch.cuda.empty_cache()
+    return _CACHE[("dense", seed)]
+
+
+def _oracle(kind, budget, hw=64, grads=True):
+    """(losses, {name: grad}) of the CPU oracle for one step kind; computed once per module run."""
+    key = (kind, budget, hw, grads)
+    if key in _CACHE:
+        return _CACHE[key]
+    from pdm_ref import step as ostep, weights as oweights
+    from pdm_ref.config import UNetConfig as OCfg
+    from pdm.models.unet.spec import UNetConfig, arch_vector_for_budget
+    ocfg, cfg = OCfg.sd21(), UNetConfig.sd21()
+    dense = _dense()
+    if budget >= 1.0:      # dense student with its OWN weights (seed 1), so that the distillation / block terms are not 0
+        psd, info, av = _dense(1), oweights.dense_info(ocfg), None
+    else:
+        av = arch_vector_for_budget(cfg, budget, hw=hw)[0]
+        psd, info = oweights.prune_state_dict(dense, ocfg, av)
+    lat, noise, t, ehs, empty = _inputs(hw)
+    P = {k_: (v.clone().requires_grad_(True) if grads else v) for k_, v in psd.items()}
+    tch = (dense, oweights.dense_info(ocfg))
+    with torch.set_grad_enabled(grads):
+        if kind == "main":
+            out = ostep.main_step_loss((P, info), tch, ocfg, ostep.alphas_cumprod(), lat, noise, t, ehs)
+        else:
+            out = ostep.upper_step_loss((P, info), tch, ocfg, ostep.alphas_cumprod(), lat, noise, t, ehs, empty)
+        if grads:
+            out[0].backward()
+    res = (tuple(float(x) for x in out[:4]), {n: p.grad for n, p in P.items()} if grads else None, av)
+    _CACHE[key] = res
+    return res
+
+
+def _models(dtype, av, train=True, student_sd=None):
+    from pdm.models.unet.spec import UNetConfig
+    from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+    cfg = UNetConfig.sd21()
+    dense = _dense()
+    teacher = UNet2DConditionModelPruned(cfg, None, "cuda:0", dtype, train=False, init=False)
+    teacher.load_dense_or_pruned(dense)
+    student = UNet2DConditionModelPruned(cfg, av, "cuda:0", dtype, train=train, init=False)
+    student.load_dense_or_pruned(dense if student_sd is None else student_sd)
+    return student, teacher
+
+
+def _check_grads(student, ref, dn):
+    got = student.store.state_dict(arena=student.store.grad)
+    assert set(got) == set(ref)
+    missing = [n for n in NAMED if n not in ref]
+    assert not missing, missing
+    bad = []
+    if dn == "f32":
+        for n, g in ref.items():
+            tol = 2e-3 if n in NAMED else 1e-2
+            r = _rel(got[n], g)
+            if not r <= tol:
+                bad.append((n, r))
+    else:
+        for n, g in ref.items():
+            if g.numel() < 4096 and n not in NAMED:
+                continue
+            cos = torch.nn.functional.cosine_similarity(got[n].flatten().double(), g.flatten().double(), dim=0).item()
+            if not cos >= (0.98 if g.numel() >= 1024 else 0.95):
+                bad.append((n, cos))
+    assert not bad, (len(bad), bad[:10])
+    # the packed arena's padding carries exactly-zero gradients at full size too
+    packed = float(student.store.grad.double().abs().sum())
+    logical = float(sum(v.double().abs().sum() for v in got.values()))
+    assert math.isfinite(packed) and abs(packed - logical) <= 1e-5 * logical
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_full_size_main_step_gradients_match_oracle(dev, dn):
+    from pdm.training.bilevel import BilevelStepper
+    (loss, diff, dist_, block), gref, av = _oracle("main", 0.55)
+    dtype = torch.float32 if dn == "f32" else torch.bfloat16
+    student, teacher = _models(dtype, av)
+    lat, noise, t, ehs, _ = _inputs()
+    st = BilevelStepper(student, teacher)
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda()))
+    tol = 1e-3 if dn == "f32" else 3e-2
+    for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
+    _check_grads(student, gref, dn)
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_full_size_upper_step_loss_and_gradients_match_oracle(dev, dn):
+    from pdm.training.bilevel import BilevelStepper
+    (loss, _, dist_, _), gref, av = _oracle("upper", 0.55)
+    dtype = torch.float32 if dn == "f32" else torch.bfloat16
+    student, teacher = _models(dtype, av)
+    lat, noise, t, ehs, empty = _inputs()
+    st = BilevelStepper(student, teacher)
+    tot, _, s, _ = st.total(st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda()), upper=True)
+    tol = 1e-3 if dn == "f32" else 3e-2
+    assert abs(tot - loss) <= tol * abs(loss), (tot, loss)
+    assert abs(s - dist_) <= tol * abs(dist_), (s, dist_)
+    _check_grads(student, gref, dn)
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_keep_018_student_main_step_losses(dev, dn):
+    """BASELINE configs[3] read as "82 % pruned" = 18 % of the MACs kept."""
+    from pdm.training.bilevel import BilevelStepper
+    (loss, diff, dist_, block), _, av = _oracle("main", 0.18, grads=False)
+    dtype = torch.float32 if dn == "f32" else torch.bfloat16
+    student, teacher = _models(dtype, av)
+    lat, noise, t, ehs, _ = _inputs()
+    st = BilevelStepper(student, teacher)
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=(dn == "bf16")))
+    tol = 1e-3 if dn == "f32" else 3e-2
+    for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
+    if dn == "bf16":
+        gsum = float(student.store.grad.double().abs().sum())
+        assert math.isfinite(gsum) and gsum > 0
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_dense_student_96x96_latents_main_step_losses(dev, dn):
+    """BASELINE configs[4] shape: dense (unpruned) student, 768^2 images = 96x96 latents, N = 9216 self-attention tokens.
+    (The config's fp8 attention is a precision option; parity is checked on the fp32 engine at 1e-3 and on the bf16 engine.)"""
+    from pdm.training.bilevel import BilevelStepper
+    (loss, diff, dist_, block), _, av = _oracle("main", 1.0, hw=96, grads=False)
+    dtype = torch.float32 if dn == "f32" else torch.bfloat16
+    student, teacher = _models(dtype, None, student_sd=_dense(1))
+    lat, noise, t, ehs, _ = _inputs(96)
+    st = BilevelStepper(student, teacher)
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=(dn == "bf16")))
+    tol = 1e-3 if dn == "f32" else 3e-2
+    for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
+        assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
+    if dn == "bf16":
+        gsum = float(student.store.grad.double().abs().sum())
+        assert math.isfinite(gsum) and gsum > 0

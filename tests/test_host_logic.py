@@ -14,12 +14,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cabi_library_exports_every_declared_symbol():
     from pdm import _pdmk
     hdr = open(os.path.join(ROOT, "include", "pdmk.h")).read()
-    declared = set(re.findall(r"^int (pdmk_\w+)\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t) (pdmk_\w+)\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_pdmk.EXPORTS), declared ^ set(_pdmk.EXPORTS)
     for name in declared:
         assert hasattr(_pdmk._lib, name)
     assert _pdmk.version() >= 100
+
+
+def test_workspace_queries_and_plan_file_roundtrip(tmp_path):
+    """The *_workspace_bytes() queries answer without a GPU; the plan cache round-trips through its file."""
+    from pdm import _pdmk as k
+    L = k._lib
+    assert L.pdmk_gemm_splitk_workspace_bytes(2048, 1280, 3) == 3 * 2048 * 1280 * 4
+    assert L.pdmk_gemm_splitk_workspace_bytes(0, 8, 1) == -1
+    assert L.pdmk_groupnorm_workspace_bytes(8, 32) == 8 * 32 * 64 * 8
+    assert L.pdmk_groupnorm_bwd_part_workspace_bytes(32, 80) == 2048 * 2 * 2560 * 4
+    assert L.pdmk_layernorm_bwd_part_workspace_bytes(32768, 320) == (32768 // 16 + 1) * 2 * 320 * 4
+    assert L.pdmk_attn_bwd_workspace_bytes(8, 5, 4096, 77) == 2 * 16 * 8 * 5 * 77 * 64 * 4
+    assert L.pdmk_attn_bwd_workspace_bytes(8, 5, 4096, 4096) == 0
+    f = tmp_path / "plans.txt"
+    f.write_text(f"pdmk-plan {k.version()}\nc 1 2 3 0 0 0 0 0 0 1 7\ns 1 2 3 0 0 0 0 0 0 0 2\n")
+    k.plan_clear()
+    assert k.plan_import(str(f)) == 2 and k.plan_size() == 2
+    g = tmp_path / "out.txt"
+    k.plan_export(str(g))
+    assert sorted(g.read_text().splitlines()) == sorted(f.read_text().splitlines())
+    (tmp_path / "old.txt").write_text("pdmk-plan 1\nc 1 2 3 0 0 0 0 0 0 1 7\n")
+    try:
+        k.plan_import(str(tmp_path / "old.txt"))
+        raise AssertionError("a plan file of another build must be refused")
+    except k.PdmkError:
+        pass
+    k.plan_clear()
+    assert k.plan_size() == 0
 
 
 def test_structure_matches_oracle_and_reference_sizes():

@@ -161,7 +161,7 @@ def test_upper_step_matches_oracle(dev, dn):
         assert cos > 0.98, cos
 
 
-@pytest.mark.parametrize("dn,budget", [("f32", 0.55), ("bf16", 0.55), ("bf16", 0.82)])
+@pytest.mark.parametrize("dn,budget", [("bf16", 0.82)])    # budget 0.55 (+ gradients, upper step, 96^2): test_fullsize_parity_gpu.py
 def test_full_size_sd21_main_step_matches_oracle(dev, dn, budget):
     """BASELINE.json configs[0] (and the 82 %-budget student of configs[3]): the REAL SD-2.1 topology (865.9 M-parameter
     dense teacher, MAC-budget-0.55 / 0.82 student),
@@ -281,14 +281,19 @@ def test_streamed_adamw_matches_step_then_optimizer(dev, forced):
         assert d.mean().item() <= 2e-3 * a.abs().mean().item() + 1e-6, (what, d.mean().item(), a.abs().mean().item())
 
 
-def test_bilevel_loss_curve_matches_oracle_fp32(dev):
-    """north_star: "loss curves matching the CPU reference to 1e-3".  Nine bilevel iterations on the tiny topology in the
-    fp32 engine - main step + AdamW every iteration, upper (concept-suppression) step + its own AdamW every third, fresh
-    seeded (latent, noise, timestep, prompt) inputs per iteration - against the same loop on the CPU oracle
-    (autograd + the oracle's AdamW restatement).  Every loss of both curves must agree to 1e-3 relative."""
+@pytest.mark.parametrize("dn,tol", [("f32", 1e-3), ("bf16", 2e-2)])
+def test_bilevel_loss_curve_matches_oracle(dev, dn, tol):
+    """north_star: "loss curves matching the CPU reference to 1e-3".  Nine bilevel iterations on the tiny topology - main
+    step + AdamW every iteration, upper (concept-suppression) step + its own AdamW every third, fresh seeded (latent,
+    noise, timestep, prompt) inputs per iteration - against the same loop on the fp32 CPU oracle (autograd + the oracle's
+    AdamW restatement).  fp32 engine: every loss of both curves agrees to 1e-3 relative.  bf16 engine (the benchmarked
+    dtype: bf16 weights / activations, fp32 accumulation, statistics, master weights and optimiser): 2e-2 - one bf16
+    rounding is 2^-9 = 2e-3 relative and a loss is a mean of squared O(1) differences behind ~100 rounded layers, so the
+    curve cannot track an fp32 reference to 1e-3; what it must not do is DRIFT: the bound is the same at iteration 9 as
+    at iteration 1 (fp32 master weights, so rounding does not accumulate in the parameters)."""
     from pdm_ref import step as ostep, weights as oweights
     from pdm.training.bilevel import BilevelStepper
-    ocfg, dense, psd, info, student, teacher = _setup(torch.float32, drop_depth=(1, 9))
+    ocfg, dense, psd, info, student, teacher = _setup(torch.float32 if dn == "f32" else torch.bfloat16, drop_depth=(1, 9))
     ac = ostep.alphas_cumprod()
     lr, ulr = 2e-5, 5e-5
     st = BilevelStepper(student, teacher, lr=lr, upper_lr=ulr, bilevel=True)
@@ -320,7 +325,7 @@ def test_bilevel_loss_curve_matches_oracle_fp32(dev):
             ref_curve.append(loss.item())
     assert len(curve) == 12
     worst = max(abs(got - ref) / max(abs(ref), 1e-6) for (_, got), ref in zip(curve, ref_curve))
-    assert worst <= 1e-3, [(n, round(got, 6), round(ref, 6)) for (n, got), ref in zip(curve, ref_curve)]
+    assert worst <= tol, [(n, round(got, 6), round(ref, 6)) for (n, got), ref in zip(curve, ref_curve)]
     # the curves must actually move (the optimisers are live): last main loss differs from a frozen-weights evaluation
     new = student.state_dict()
     drift = max((new[n] - psd[n]).abs().max().item() for n in psd)

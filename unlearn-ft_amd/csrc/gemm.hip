@@ -835,4 +835,55 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 105; }
+/* Plan-cache control (include/pdmk.h): the cache is process-global state behind g_plan_mu. */
+extern "C" int pdmk_plan_size(void) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    return (int)(g_plan_cfg.size() + g_plan_sk.size());
+}
+extern "C" int pdmk_plan_export(const char* path) {
+    if (!path) return -1;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    FILE* f = fopen(path, "w");
+    if (!f) return -1;
+    fprintf(f, "pdmk-plan %d\n", pdmk_version());
+    for (int pass = 0; pass < 2; ++pass)
+        for (const auto& kv : (pass ? g_plan_sk : g_plan_cfg)) {
+            const PlanKey& k = kv.first;
+            fprintf(f, "%c %d %d %d %d %d %d %d %d %d %d %d\n", pass ? 's' : 'c', k.v[0], k.v[1], k.v[2], k.v[3], k.v[4], k.v[5],
+                    k.v[6], k.v[7], k.v[8], k.v[9], kv.second);
+        }
+    return fclose(f) == 0 ? 0 : -1;
+}
+extern "C" int pdmk_plan_import(const char* path) {
+    if (!path) return -1;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    FILE* f = fopen(path, "r");
+    if (!f) return -1;
+    int ver = 0;
+    if (fscanf(f, " pdmk-plan %d", &ver) != 1 || ver != pdmk_version()) {
+        fclose(f);
+        return -2;                                       // candidate numbering of another build
+    }
+    char kind;
+    PlanKey k;
+    int val, n = 0;
+    while (fscanf(f, " %c %d %d %d %d %d %d %d %d %d %d %d", &kind, &k.v[0], &k.v[1], &k.v[2], &k.v[3], &k.v[4], &k.v[5],
+                  &k.v[6], &k.v[7], &k.v[8], &k.v[9], &val) == 12) {
+        if (kind == 'c') g_plan_cfg[k] = val;
+        else if (kind == 's') g_plan_sk[k] = val;
+        ++n;
+    }
+    fclose(f);
+    return n;
+}
+extern "C" int pdmk_plan_clear(void) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    g_plan_cfg.clear();
+    g_plan_sk.clear();
+    if (g_scratch) (void)hipFree(g_scratch);
+    g_scratch = nullptr;
+    g_scratch_bytes = 0;
+    return 0;
+}
+
+extern "C" int pdmk_version(void) { return 106; }

@@ -82,6 +82,15 @@ _SIGS = {
     "pdmk_embed_tokens": ([vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd_causal": ([vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
     "pdmk_gelu_fwd": ([vp, vp, i64, i32, vp], i32),
+    "pdmk_gemm_splitk_workspace_bytes": ([i64, i32, i32], i64),
+    "pdmk_groupnorm_workspace_bytes": ([i32, i32], i64),
+    "pdmk_groupnorm_bwd_part_workspace_bytes": ([i32, i32], i64),
+    "pdmk_layernorm_bwd_part_workspace_bytes": ([i32, i32], i64),
+    "pdmk_attn_bwd_workspace_bytes": ([i32, i32, i32, i32], i64),
+    "pdmk_plan_export": ([C.c_char_p], i32),
+    "pdmk_plan_import": ([C.c_char_p], i32),
+    "pdmk_plan_size": ([], i32),
+    "pdmk_plan_clear": ([], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
     _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
@@ -144,6 +153,39 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     e1.record()
     kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode, _lib.pdmk_gemm_last_candidate())
     PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
+
+
+def _ws_bytes(n):
+    if n < 0:
+        raise PdmkError("workspace query rejected its arguments")
+    return int(n)
+
+
+def plan_export(path):
+    _chk(_lib.pdmk_plan_export(os.fsencode(path)), "pdmk_plan_export")
+
+
+def plan_import(path):
+    n = _lib.pdmk_plan_import(os.fsencode(path))
+    if n < 0:
+        raise PdmkError(f"pdmk_plan_import({path!r}) failed with status {n}")
+    return n
+
+
+def plan_size():
+    return int(_lib.pdmk_plan_size())
+
+
+def plan_clear():
+    _chk(_lib.pdmk_plan_clear(), "pdmk_plan_clear")
+
+
+def groupnorm_ws(device, B, G, have=None):
+    """fp64 scratch of pdmk_groupnorm_fwd / _bwd, sized by the library; `have` is returned when it is already big enough."""
+    need = _ws_bytes(_lib.pdmk_groupnorm_workspace_bytes(B, G)) // 8
+    if have is not None and have.numel() >= need:
+        return have
+    return torch.empty(max(need, 1 << 17), device=device, dtype=torch.float64)
 
 
 def zeros(shape, device, dtype):
@@ -216,7 +258,7 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
                     a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs, ldrv=ldrv)
     # split-K: every split stores its fp32 partial into its own slab (plain stores: no atomics, no zero-fill, the sum
     # order is fixed), the finish pass adds the slabs and applies the epilogue
-    ws = torch.empty((sk, M, N), device=A.device, dtype=torch.float32)
+    ws = torch.empty(_ws_bytes(_lib.pdmk_gemm_splitk_workspace_bytes(M, N, sk)) // 4, device=A.device, dtype=torch.float32)
     gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, accumulate=2, macs=macs)
     splitk_finish(ws, Cout, M, N, ldc, sk, bias=bias, rowvec=rowvec, R=R, ldr=ldr, rows_per_b=rows_per_b, ldrv=ldrv,
                   accumulate=accumulate)
@@ -256,7 +298,7 @@ def part_ws(device, elems):
 
 
 def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc):
-    pw = part_ws(x.device, 2048 * 2 * G * gs)
+    pw = part_ws(x.device, _ws_bytes(_lib.pdmk_groupnorm_bwd_part_workspace_bytes(G, gs)) // 4)
     _chk(_lib.pdmk_groupnorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), _p(ws),
                                  _p(pw), pw.numel(), B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), dt(x),
                                  _st()), "pdmk_groupnorm_bwd")
@@ -268,7 +310,7 @@ def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
 
 
 def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc):
-    pw = part_ws(x.device, (M // 16 + 1) * 2 * Cc)
+    pw = part_ws(x.device, _ws_bytes(_lib.pdmk_layernorm_bwd_part_workspace_bytes(M, Cc)) // 4)
     _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), _p(pw),
                                  pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
 
@@ -280,9 +322,8 @@ def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale):
 
 
 def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_, dqs, dks, dvs, scale):
-    ws = None
-    if Nk <= 128 and Nq >= 512:          # cross-attention: few keys -> the dK/dV pass also splits the queries (pdmk.h)
-        ws = torch.empty(2 * 16 * B * H * Nk * 64, device=q.device, dtype=torch.float32)
+    nws = _ws_bytes(_lib.pdmk_attn_bwd_workspace_bytes(B, H, Nq, Nk)) // 4   # > 0: few keys, the dK/dV pass also splits the queries
+    ws = torch.empty(nws, device=q.device, dtype=torch.float32) if nws else None
     _chk(_lib.pdmk_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), B, H, Nq,
                             Nk, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], dqs[0], dqs[1], dks[0],
                             dks[1], dvs[0], dvs[1], scale, _p(ws), 0 if ws is None else ws.numel(), dt(q), _st()),

@@ -36,7 +36,7 @@ class UNetEngine:
         half = cfg.block_out_channels[0] // 2
         # frequency table of Timesteps(dim, flip_sin_to_cos=True, shift=0): built exactly like the reference (fp32 exp)
         self.freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(self.dev)
-        self.ws = torch.zeros(1 << 17, device=self.dev, dtype=torch.float64)   # GN scratch: >= B*G*64 doubles
+        self.ws = k.groupnorm_ws(self.dev, 64, cfg.norm_num_groups)      # GN scratch, regrown by groupnorm() if B asks for more
         self.tape = []
         self.train = False
         self.macs = 0
@@ -223,6 +223,7 @@ class UNetEngine:
         y = self._empty(B * HW, C)
         stats = torch.empty((B, G, 2), device=self.dev, dtype=torch.float32)
         gw, gb = P.p(key + ".weight"), P.p(key + ".bias")
+        self.ws = k.groupnorm_ws(self.dev, B, G, self.ws)
         k.groupnorm_fwd(x.t, y, gw, gb, stats, self.ws, B, HW, C, _ld(x.t), C, G, gs, eps, silu)
         out = Act(y)
         if self.train:

@@ -112,7 +112,7 @@ class _Ops(UNetEngine):
     def __init__(self, store, dtype):
         self.cfg, self.blocks, self.P, self.dtype = None, None, store, dtype
         self.dev = store.master.device
-        self.ws = torch.zeros(1 << 17, device=self.dev, dtype=torch.float64)
+        self.ws = k.groupnorm_ws(self.dev, 64, 32)
         self.tape, self.train, self.macs, self.count_macs = [], False, 0, False
         self.grad_ready_cb, self.wgrad_async, self._keep = None, False, []
 
