@@ -69,8 +69,49 @@ def cpu_baseline(budget, latent, tiny):
                       f"{latent}x{latent} latent, fp32, pure-torch CPU oracle; {dt_:.1f} s"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` from a bare shell (no torchrun): start one child process per GPU with the torchrun
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), wait for them and return the worst exit code.  The parent
+    never initialises the GPU and never execs; rank 0's child prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("PDMK_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()           # does not initialise the GPU
+    if not rehearsal and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible (PDMK_BENCH_REHEARSAL=1 rehearses the "
+                         f"N-rank path with every rank on cuda:0 over gloo)")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p_ in list(procs):
+                r_ = p_.poll()
+                if r_ is None:
+                    continue
+                procs.remove(p_)
+                if r_ != 0:                    # one rank died: the others would hang in a collective
+                    rc = rc or r_
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,9 +174,33 @@ def main():
     # --no_graph: eager launches (all-reduce buckets issued from the backward tape).
     use_graph = not a.no_graph
     graphs = None
-    if use_graph:
-        graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
-        graphs.capture(bilevel=True)
+    # every rank launches the SAME kernels: rank 0 warms up first (its library times the GEMM candidates of every shape of
+    # the step), exports its plan cache, and the other ranks import it before their own warm-up - no rank-to-rank skew from
+    # differently tuned plans, and the same split-K sums everywhere
+    plan_file = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pdmk_plans_{os.environ.get('MASTER_PORT', '0')}.txt")
+
+    def warm():
+        nonlocal graphs
+        if use_graph:              # (--no_graph: plans are made by the untimed warm-up iterations, rank by rank)
+            graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
+            graphs.capture(bilevel=True)
+
+    if world > 1 and use_graph:
+        if rank == 0:
+            warm()
+            k.plan_export(plan_file)
+        dist.barrier()
+        if rank != 0:
+            k.plan_import(plan_file)
+            warm()
+        dist.barrier()
+        if rank == 0:
+            try:
+                os.remove(plan_file)
+            except OSError:
+                pass
+    else:
+        warm()
 
     def bilevel_iter(i):
         d, u = data[i % nb], data[(i + 1) % nb]

@@ -1,0 +1,112 @@
+"""One data-parallel rank of tests/test_dp_equivalence_gpu.py (not a test module).
+
+Rehearsal of the N-rank path on a one-GPU box: every rank sits on cuda:0 and the process group is gloo (the product
+path is the same code over RCCL).  The global batch of 4 samples is split row-wise over `world` ranks; every rank runs
+3 bilevel iterations (main step + AdamW each, upper step + its AdamW on the third) of the tiny fp32 engine, eager from the
+backward tape or as segmented hipGraph replay, and rank 0 saves:
+  grad   the rank-mean gradient arena after the first main step's backward + all-reduce (before any optimiser step)
+  master the fp32 master arena after the 3 iterations
+Reference: DDP wrap + accelerator.backward, pdm/training/trainer.py:117-129, 2719-2724, 2782, 2808.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p_ in (os.path.join(ROOT, "unlearn-ft_amd"), os.path.join(ROOT, "oracle")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GLOBAL_B, ITERS, UPPER_AT = 4, 3, 2
+LR, UPPER_LR = 1e-4, 2e-4
+
+
+def global_batches():
+    g = torch.Generator().manual_seed(97)
+    out = []
+    for _ in range(ITERS + 1):
+        out.append(dict(lat=torch.randn(GLOBAL_B, 4, 16, 16, generator=g), noise=torch.randn(GLOBAL_B, 4, 16, 16, generator=g),
+                        t=torch.randint(0, 1000, (GLOBAL_B,), generator=g), ehs=torch.randn(GLOBAL_B, 13, 64, generator=g),
+                        empty=torch.randn(1, 13, 64, generator=g).expand(GLOBAL_B, 13, 64).contiguous()))
+    return out
+
+
+def run(mode, world, rank, out=None):
+    from pdm_ref import arch as oarch, weights as oweights
+    from pdm_ref.config import UNetConfig as OCfg
+    from pdm import _pdmk as k
+    from pdm.models.unet.spec import UNetConfig
+    from pdm.models.unet.unet_2d_conditional import UNet2DConditionModelPruned
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
+    ocfg, cfg = OCfg.tiny(), UNetConfig.tiny()
+    dense = oweights.init_dense_state_dict(ocfg, seed=0)
+    av = oarch.random_arch_vector(ocfg, 0.55, seed=0, drop_depth=(1, 9))
+    student = UNet2DConditionModelPruned(cfg, av, "cuda:0", torch.float32, train=True, init=False)
+    student.load_dense_or_pruned(dense)
+    teacher = UNet2DConditionModelPruned(cfg, None, "cuda:0", torch.float32, train=False, init=False)
+    teacher.load_dense_or_pruned(dense)
+    st = BilevelStepper(student, teacher, lr=LR, upper_lr=UPPER_LR, bilevel=True, bucket_mb=1)
+    st.reducer.bucket = max(1024, student.store.total // 5)        # several buckets + a ragged head on the tiny arena
+    assert st.world == world
+    B = GLOBAL_B // world
+    rows = slice(rank * B, (rank + 1) * B)
+    data = [{n: v[rows].cuda() for n, v in d.items()} for d in global_batches()]
+    store = student.store
+    init = store.master.clone()
+    graphs = None
+    if mode == "graph":
+        graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True)
+        graphs.force_segments = True            # world 1 takes the multi-graph replay path too
+        graphs.capture(bilevel=True)
+        assert len(graphs.g_main) == 3
+        assert torch.equal(store.master, init)  # capture restored the training state
+    # ---- gradient of the first main step, reduced over the ranks, no optimiser
+    d = data[ITERS]
+    if graphs is None:
+        st.main_step(d["lat"], d["noise"], d["t"], d["ehs"])
+        scale = st._gscale
+    else:
+        graphs._load(d["lat"], d["noise"], d["t"], d["ehs"])
+        graphs._replay_step(graphs.g_main, graphs.main_offs, None)
+        scale = 1.0 / world
+    torch.cuda.synchronize()
+    grad = (store.grad * scale).cpu()
+    k.zero_(store.grad)
+    # ---- 3 bilevel iterations
+    for it in range(ITERS):
+        d = data[it]
+        if graphs is None:
+            st.main_step(d["lat"], d["noise"], d["t"], d["ehs"])
+            st.optimizer_step(upper=False)
+            if it == UPPER_AT:
+                st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
+                st.optimizer_step(upper=True)
+        else:
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
+            if it == UPPER_AT:
+                graphs.upper(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
+    torch.cuda.synchronize()
+    res = {"grad": grad, "master": store.master.cpu(), "init": init.cpu(), "lr": st.opt.current_lr()}
+    if out and rank == 0:
+        torch.save(res, out)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", required=True, choices=["eager", "graph"])
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    run(a.mode, world, rank, a.out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,3 +52,40 @@ def test_bucketed_allreduce_world2_gloo():
     assert all(ok for _, ok, _ in res), res
     assert all(abs(s - 0.5) < 1e-12 for _, _, s in res), res
     assert all(p.exitcode == 0 for p in ps)
+
+
+def test_bench_self_launch_sets_the_rank_environment(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` from a bare shell: the parent starts N children with the torchrun environment, never
+    touches the GPU itself and returns the worst exit code.  Here the child is replaced by a stub that records its
+    environment (no GPU in this container), which is exactly what the launcher hands to the real ranks."""
+    import importlib.util
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os, sys\n"
+                    "open(os.path.join(os.environ['STUB_DIR'], 'r' + os.environ['RANK']), 'w').write(' '.join(\n"
+                    "    os.environ[k] for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')) + '|' + ' '.join(sys.argv[1:]))\n"
+                    "sys.exit(3 if os.environ['RANK'] == '1' and os.environ.get('STUB_FAIL') else 0)\n")
+    real_popen = subprocess.Popen
+    monkeypatch.setattr(subprocess, "Popen", lambda cmd, env=None, **kw: real_popen([cmd[0], str(stub)] + cmd[2:], env=env, **kw))
+    monkeypatch.setenv("STUB_DIR", str(tmp_path))
+    monkeypatch.setenv("PDMK_BENCH_REHEARSAL", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=2)) == 0
+    recs = [(tmp_path / f"r{r}").read_text() for r in range(2)]
+    envs = [r.split("|")[0].split() for r in recs]
+    assert [e[0] for e in envs] == ["0", "1"] and all(e[2] == "2" and e[3] == "127.0.0.1" for e in envs)
+    assert envs[0][4] == envs[1][4] and all(r.endswith("--gpus 2 --steps 3") for r in recs)
+    monkeypatch.setenv("STUB_FAIL", "1")
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=2)) == 3
+    # without rehearsal mode the launcher refuses to start more ranks than there are GPUs (none in this container)
+    monkeypatch.delenv("PDMK_BENCH_REHEARSAL")
+    import pytest
+    with pytest.raises(SystemExit):
+        bench.launch_ranks(types.SimpleNamespace(gpus=2))

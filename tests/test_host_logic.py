@@ -147,3 +147,52 @@ def test_empty_batch_rule_follows_the_reference():
     assert not Trainer._is_empty({"pixel_values": torch.zeros(1, 3, 8, 8), "prompt_embeds": z})
     assert Trainer._is_empty({"latents": z}) and not Trainer._is_empty({"latents": torch.zeros(1, 4, 8, 8)})
     assert Trainer._is_empty({"input_ids": torch.zeros(0, 77, dtype=torch.int64)}) and Trainer._is_empty({})
+
+
+def test_optimizer_state_uses_the_torch_adamw_layout_in_reference_parameter_order():
+    """optimizer.bin / scheduler.bin interchange (trainer.py:452-514): FusedAdamW.state_dict() is what
+    torch.optim.AdamW.state_dict() would be for the reference module - loadable by a torch AdamW over parameters in the
+    reference's registration order - and it round-trips through the packed arenas bit-exactly."""
+    from pdm.models.unet import spec
+    from pdm.models.unet.params import ParamStore, build_entries, reference_param_order
+    from pdm.training.bilevel import FusedAdamW
+    cfg = spec.UNetConfig.tiny()
+    av = oarch.random_arch_vector(OCfg.tiny(), 0.6, seed=3, drop_depth=(1, 9))
+    blocks = spec.apply_arch_vector(cfg, av)
+    store = ParamStore(build_entries(cfg, blocks), "cpu", torch.float32, train=True)
+    dense = oweights.init_dense_state_dict(OCfg.tiny(), seed=0)
+    psd, _ = oweights.prune_state_dict(dense, OCfg.tiny(), av)
+    store.load_state_dict(psd, refresh=False)
+    names = store.state_dict_names()
+    order = reference_param_order(names)
+    assert sorted(order) == sorted(psd) and order[0] == "conv_in.weight" and order[-1] == "conv_out.bias"
+    # attentions before resnets inside a block, up_blocks before mid_block (registration order of the reference module)
+    assert order.index("down_blocks.0.attentions.0.norm.weight") < order.index("down_blocks.0.resnets.0.norm1.weight")
+    assert order.index("up_blocks.3.resnets.0.norm1.weight") < order.index("mid_block.attentions.0.norm.weight")
+    opt = FusedAdamW(store, 3e-4, warmup_steps=10)
+    g = torch.Generator().manual_seed(1)
+    # random moments inside the logical (unpadded) region only: export + import of a state dict cannot carry padding
+    m_sd = {n: torch.randn(v.shape, generator=g) for n, v in psd.items()}
+    v_sd = {n: torch.rand(v.shape, generator=g) for n, v in psd.items()}
+    store.load_state_dict(m_sd, arena=opt.m)
+    store.load_state_dict(v_sd, arena=opt.v)
+    opt.t, opt.sched_k = 3, 3
+    sd = opt.state_dict()
+    params = [torch.nn.Parameter(psd[n].clone()) for n in order]
+    topt = torch.optim.AdamW(params, lr=3e-4, weight_decay=0.0)
+    topt.load_state_dict(sd)                                     # torch accepts it as its own
+    assert float(topt.state[params[5]]["step"]) == 3.0
+    assert torch.equal(topt.state[params[5]]["exp_avg"], m_sd[order[5]])
+    assert abs(topt.param_groups[0]["lr"] - 3e-4 * 0.3) < 1e-12 and topt.param_groups[0]["initial_lr"] == 3e-4
+    sch = torch.optim.lr_scheduler.LambdaLR(topt, lambda k_: min(1.0, k_ / 10.0))
+    sch.load_state_dict(opt.scheduler_state_dict())
+    assert sch.last_epoch == 3
+    # and what torch writes comes back into the packed arenas
+    opt2 = FusedAdamW(store, 3e-4, warmup_steps=10)
+    opt2.load_state_dict(topt.state_dict())
+    opt2.load_scheduler_state_dict(sch.state_dict())
+    assert opt2.t == 3 and opt2.sched_k == 3 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    fresh = FusedAdamW(store, 3e-4)
+    assert fresh.state_dict()["state"] == {}                     # no step taken: empty state, like torch
+    opt2.load_state_dict(fresh.state_dict())
+    assert opt2.t == 0 and float(opt2.m.abs().max()) == 0.0

@@ -136,3 +136,83 @@ def test_pndm_reduces_to_ddim_and_reproduces_constant_predictions():
         for tt in sorted(set(seen), reverse=True):
             ref = PNDM(prediction_type=pt).get_prev_sample(ref, tt, tt - 100, c.double())
         assert torch.allclose(lat.double(), ref, atol=1e-5), pt
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tests/golden/reference_pruning.json: outputs of the REFERENCE'S OWN method bodies (hypernet.py:100-150 classmethods and
+# the four prune() methods of blocks.py), executed in the build container by oracle/pin_reference_pruning.py.
+def _digest(t):
+    import hashlib
+    t = t.detach().to(torch.float32).contiguous()
+    return [list(t.shape), hashlib.sha256(t.numpy().tobytes()).hexdigest()]
+
+
+def _pruning_fixture():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_pruning.json")))
+
+
+def test_arch_vector_classmethods_match_reference_outputs():
+    """HyperStructure.get_random_arch_vector / transform_arch_vector (incl. force_width_non_zero): the oracle's and the
+    product's restatements reproduce the reference's outputs bit for bit on the same seeds."""
+    from pdm.models.unet import spec
+    fx = _pruning_fixture()["arch"]
+    assert len(fx) == 8
+    for rec in fx:
+        ocfg = getattr(UNetConfig, rec["cfg"])()
+        pcfg = getattr(spec.UNetConfig, rec["cfg"])()
+        for structure in (arch.structure(ocfg), spec.gate_structure(pcfg)):
+            torch.manual_seed(rec["seed"])                       # the reference draws from the global generator
+            av = spec.get_random_arch_vector(rec["ratio"], structure)
+            assert _digest(av) == rec["random_arch_vector"], (rec["cfg"], rec["seed"])
+            assert int((av >= 0.5).sum()) == rec["kept"]
+        n = rec["n"]
+        g = torch.Generator().manual_seed(rec["transform_input_seed"])
+        x = torch.rand(1, n, generator=g)
+        structure = spec.gate_structure(pcfg)
+        w1 = structure["width"][0][0] + (structure["width"][0][1] if len(structure["width"][0]) > 1 else structure["width"][1][0])
+        x[0, :w1] = 0.3 * x[0, :w1]                              # first two gates entirely below the threshold
+        for force in (False, True):
+            want = rec[f"transform_force{int(force)}"]
+            xin = spec.force_width_non_zero(x, structure) if force else x
+            for name, tv in (("product", spec.transform_arch_vector(xin, structure)),
+                             ("oracle", arch.transform_arch_vector(xin, ocfg))):
+                assert len(tv["width"]) == want["nwidth"] and len(tv["depth"]) == want["ndepth"], name
+                assert [_digest(w) for w in tv["width"]] == want["width"], (name, force)
+                assert [_digest(d) for d in tv["depth"]] == want["depth"], (name, force)
+        assert rec["transform_force1"]["first_elems"][0] != rec["transform_force0"]["first_elems"][0]    # the branch fired
+
+
+def test_physical_pruning_matches_reference_prune_methods():
+    """ResnetBlock2DWidth[Depth]Gated.prune, GatedAttention.prune, GEGLUGated.prune_gate + FeedForwardWidthGated.prune run
+    on the tiny topology's seeded dense weights: the oracle's prune_state_dict yields bit-identical tensors (sha256), the
+    same kept-head / kept-group counts and the same dropped blocks - and so does the product's slice_dense_state_dict."""
+    from pdm.models.unet import spec
+    from pdm.models.unet.unet_2d_conditional import slice_dense_state_dict
+    cases = _pruning_fixture()["pruning"]
+    assert len(cases) == 3
+    ocfg, pcfg = UNetConfig.tiny(), spec.UNetConfig.tiny()
+    for c in cases:
+        dense = weights.init_dense_state_dict(ocfg, seed=c["dense_seed"])
+        av = arch.random_arch_vector(ocfg, c["ratio"], seed=c["arch_seed"], drop_depth=tuple(c["drop_depth"]))
+        assert _digest(av) == c["arch_vector"]
+        psd, info = weights.prune_state_dict(dense, ocfg, av)
+        prod = slice_dense_state_dict(dense, pcfg, spec.apply_arch_vector(pcfg, av))
+        ref = c["tensors"]
+        dropped = {k for k, v in ref.items() if v == "dropped"}
+        assert dropped == {p for p, i in info.items() if i["dropped"]}
+        assert len(dropped) == len(c["drop_depth"])
+        n = 0
+        for name, want in ref.items():
+            if want == "dropped":
+                assert not any(k.startswith(name + ".") for k in psd) and not any(k.startswith(name + ".") for k in prod)
+            elif name.endswith(".heads"):
+                blk, an = name.rsplit(".transformer_blocks.0.", 1)[0], name.split(".")[-2]
+                assert info[blk]["heads1" if an == "attn1" else "heads2"] == want
+            elif name.endswith(".num_groups"):
+                assert info[name[:-len(".norm2.num_groups")]]["groups2"] == want
+            else:
+                assert _digest(psd[name]) == want, name
+                assert _digest(prod[name]) == want, name
+                n += 1
+        assert n > 300

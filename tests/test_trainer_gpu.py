@@ -42,15 +42,76 @@ def test_bilevel_trainer_runs_logs_checkpoints_and_resumes(dev, tmp_path):
     assert recs[0]["finetuning/prediction_model_lr"] == 0.0 and recs[-1]["finetuning/prediction_model_lr"] == 1e-4
     ck = tmp_path / "checkpoint-6"
     for f in ("unet/diffusion_pytorch_model.safetensors", "unet/config.json", "arch_vector.pt", "optimizer.bin",
-              "optimizer_1.bin", "random_states_0.pkl"):
+              "optimizer_1.bin", "scheduler.bin", "scheduler_1.bin", "random_states_0.pkl"):
         assert (ck / f).exists(), f
     assert (tmp_path / "checkpoint-4").exists()
+    # optimizer.bin / scheduler.bin are what accelerator.save_state writes (trainer.py:452-477): a torch AdamW over the
+    # student's parameters in the reference module's order loads them as they are, and so does a LambdaLR
+    from pdm.models.unet.params import reference_param_order
+    sd = tr.prediction_model.state_dict()
+    order = reference_param_order(list(sd))
+    assert order[0] == "conv_in.weight" and order[-1] == "conv_out.bias" and len(order) == len(sd)
+    params = [torch.nn.Parameter(sd[n].clone()) for n in order]
+    for fname, t_steps, base in (("optimizer.bin", 6, 1e-4), ("optimizer_1.bin", 2, 5e-4)):
+        osd = torch.load(ck / fname, weights_only=False)
+        topt = torch.optim.AdamW(params, lr=base, weight_decay=0.0)
+        topt.load_state_dict(osd)
+        st0 = topt.state[params[0]]
+        assert float(st0["step"]) == t_steps and st0["exp_avg"].shape == params[0].shape
+        assert all(topt.state[p]["exp_avg_sq"].shape == p.shape for p in params)
+        sch = torch.optim.lr_scheduler.LambdaLR(topt, lambda k_: min(1.0, k_ / 2.0))
+        sch.load_state_dict(torch.load(ck / fname.replace("optimizer", "scheduler"), weights_only=False))
+        assert sch.last_epoch == t_steps and sch.get_last_lr() == [base]
+    m_before = tr.stepper.opt.m.clone()
     # resume: weights and optimiser step counters come back, global_step parsed from the directory name
     tr2 = NudityBilevelUnetFineTuner(_config(tmp_path, 8, resume="latest"))
     tr2.load_checkpoint()
     assert tr2.global_step == 6 and tr2.stepper.opt.t == 6 and tr2.stepper.upper_opt.t == 2
+    assert tr2.stepper.opt.sched_k == 6 and tr2.stepper.upper_opt.sched_k == 2
+    assert torch.equal(tr2.stepper.opt.m, m_before) and torch.equal(tr2.stepper.upper_opt.v, tr.stepper.upper_opt.v)
+    assert torch.equal(tr2.rng.get_state(), tr.rng.get_state())          # the noise / timestep stream continues
     a, b = tr.prediction_model.state_dict(), tr2.prediction_model.state_dict()
     assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_missing_weights_raise_unless_random_init_is_asked_for(dev, tmp_path):
+    """A hub id / missing directory must not silently train random weights (the reference's from_pretrained raises)."""
+    from pdm.training.trainer import BilevelUnetFineTuner
+    cfg = _config(tmp_path, 1)
+    cfg["synthetic"] = False
+    cfg["pretrained_model_name_or_path"] = "stabilityai/stable-diffusion-2-1"
+    with pytest.raises(FileNotFoundError):
+        BilevelUnetFineTuner(cfg, train_dataloader=[{}], upper_dataloader=[{}])
+    cfg["model"]["prediction_model"]["random_init"] = True           # the reference's random_init path: allowed
+    BilevelUnetFineTuner(cfg, train_dataloader=[{}], upper_dataloader=[{}])
+
+
+def test_epochs_validation_and_input_perturbation(dev, tmp_path):
+    """train() re-iterates a short dataloader until max_train_steps (epochs, trainer.py:2769-2870); validate() logs the
+    reference's validation/* keys without touching the weights; input_perturbation changes the forward process only."""
+    from pdm.training.trainer import UnetFineTuner
+    cfg = _config(tmp_path, 5)
+    tr = UnetFineTuner(cfg)
+    it = iter(tr.train_dataloader)
+    two = [next(it), next(it)]
+    tr.train_dataloader = two                                  # an "epoch" of 2 batches
+    tr.train()
+    assert tr.global_step == 5
+    w = tr.prediction_model.store.master.clone()
+    rec = tr.validate(two)
+    assert set(rec) >= {"validation/loss", "validation/diffusion_loss", "validation/distillation_loss", "validation/block_loss"}
+    assert rec["validation/loss"] > 0 and torch.equal(w, tr.prediction_model.store.master)
+    assert float(tr.prediction_model.store.grad.abs().max()) == 0.0
+    st = tr.rng.get_state()
+    base = [float(x) for x in tr.step(two[0], backward=False)]
+    tr.rng.set_state(st)
+    cfg["model"]["prediction_model"]["input_perturbation"] = 0.1
+    pert = [float(x) for x in tr.step(two[0], backward=False)]
+    assert pert[1] != base[1]
+    with pytest.raises(ValueError):
+        c2 = _config(tmp_path, 1)
+        c2["training"]["optim"]["lr_scheduler"] = "cosine"
+        UnetFineTuner(c2)
 
 
 def test_pixel_batches_go_through_the_vae(dev, tmp_path):

@@ -181,6 +181,46 @@ def build_entries(cfg: UNetConfig, blocks) -> List[Entry]:
     return E
 
 
+def reference_param_order(names):
+    """`names` (diffusers SD U-Net parameter names) in the order the reference module's `.parameters()` yields them, i.e.
+    the index a torch optimizer state dict uses.  Registration order restated from the reference's constructors:
+    pdm/models/unet/unet_2d_conditional.py:839-1167 (conv_in, time_embedding, down_blocks and up_blocks [both ModuleLists
+    are created at :966-967, before mid_block at :1043], mid_block, conv_norm_out, conv_out); block containers register
+    attentions before resnets before samplers (pdm/models/unet/blocks.py:1705-1706, 2038-2039, 2543-2544); a ResnetBlock2D
+    registers norm1, conv1, time_emb_proj, norm2, conv2, conv_shortcut; Transformer2DModel norm, proj_in,
+    transformer_blocks, proj_out; BasicTransformerBlock norm1, attn1, norm2, attn2, norm3, ff; Attention to_q, to_k, to_v,
+    to_out; weight before bias (diffusers-resident)."""
+    top = ("conv_in", "time_embedding", "down_blocks", "up_blocks", "mid_block", "conv_norm_out", "conv_out")
+    sub = ("attentions", "resnets", "downsamplers", "upsamplers")
+    leaf = ("norm1", "conv1", "time_emb_proj", "norm2", "conv2", "conv_shortcut",          # resnet
+            "norm", "proj_in", "transformer_blocks", "proj_out",                            # transformer 2D
+            "attn1", "attn2", "norm3", "ff",                                                # basic transformer block
+            "to_q", "to_k", "to_v", "to_out", "net", "proj", "conv", "linear_1", "linear_2", "weight", "bias")
+    # BasicTransformerBlock interleaves norms and attentions: norm1, attn1, norm2, attn2, norm3, ff
+    tb = {"norm1": 0, "attn1": 1, "norm2": 2, "attn2": 3, "norm3": 4, "ff": 5}
+
+    def key(name):
+        parts = name.split(".")
+        out = []
+        in_tb = False
+        for i, q in enumerate(parts):
+            if q.isdigit():
+                out.append(int(q))
+            elif i == 0:
+                out.append(top.index(q))
+            elif q in sub:
+                out.append(sub.index(q))
+            elif in_tb and q in tb:
+                out.append(tb[q])
+                in_tb = False
+            else:
+                out.append(leaf.index(q))
+            if q == "transformer_blocks":
+                in_tb = True
+        return out
+    return sorted(names, key=key)
+
+
 class ParamStore:
     """Owns the arenas of one U-Net replica.  `train=False` (teacher): master + forward copy only."""
 
@@ -269,7 +309,11 @@ class ParamStore:
 
     # ---- state dict interchange (diffusers names, pruned shapes)
     @torch.no_grad()
-    def load_state_dict(self, sd, strict=True, refresh=True):
+    def load_state_dict(self, sd, strict=True, refresh=True, arena=None):
+        """Packs diffusers-named tensors (pruned shapes) into `arena` (default: the master weights, followed by a refresh of
+        the compute copies; any other arena of the same layout - optimiser moments - is only filled).
+        Shape mismatches raise ValueError, missing / unexpected names KeyError."""
+        target = self.master if arena is None else arena
         seen = set()
         for e in self.entries:
             packed = torch.zeros(e.shape)
@@ -280,24 +324,29 @@ class ParamStore:
                 seen.add(name)
                 total = sum(r for n_, r, _, _ in e.srcs if n_ == name)
                 if e.kind == "conv3":
-                    assert t.dim() == 4 and t.shape[0] == total and t.shape[1] == e.logical[1] and t.shape[2:] == (3, 3), \
-                        f"{name}: got {tuple(t.shape)}, expected ({total},{e.logical[1]},3,3)"
+                    if not (t.dim() == 4 and t.shape[0] == total and t.shape[1] == e.logical[1] and tuple(t.shape[2:]) == (3, 3)):
+                        raise ValueError(f"{name}: got {tuple(t.shape)}, expected ({total},{e.logical[1]},3,3)")
                     t = t.permute(0, 2, 3, 1)[s0:s0 + rows]
                     packed[d0:d0 + rows, :, :t.shape[3]] = t.reshape(rows, 9, t.shape[3])
                 elif e.kind == "lin":
                     t = t.reshape(t.shape[0], -1)
-                    assert tuple(t.shape) == (total, e.logical[1]), f"{name}: got {tuple(t.shape)}, expected {(total, e.logical[1])}"
+                    if tuple(t.shape) != (total, e.logical[1]):
+                        raise ValueError(f"{name}: got {tuple(t.shape)}, expected {(total, e.logical[1])}")
                     packed[d0:d0 + rows, :t.shape[1]] = t[s0:s0 + rows]
                 else:
-                    assert tuple(t.shape) == (total,), f"{name}: got {tuple(t.shape)}, expected {(total,)}"
+                    if tuple(t.shape) != (total,):
+                        raise ValueError(f"{name}: got {tuple(t.shape)}, expected {(total,)}")
                     packed[d0:d0 + rows] = t[s0:s0 + rows]
-            self.master[e.off:e.off + e.numel].copy_(packed.reshape(-1))
+            target[e.off:e.off + e.numel].copy_(packed.reshape(-1))
         if strict:
             extra = set(sd) - seen
             if extra:
                 raise KeyError(f"unexpected keys in state dict: {sorted(extra)[:5]} ...")
-        if refresh:
+        if refresh and arena is None:
             self.refresh()
+
+    def state_dict_names(self):
+        return list(dict.fromkeys(name for e in self.entries for name, _r, _d, _s in e.srcs))
 
     @torch.no_grad()
     def state_dict(self, arena=None):

@@ -108,7 +108,7 @@ class UNet2DConditionModelPruned:
         equivalent of from_pretrained's load-then-prune, unet_2d_conditional.py:2408-2459)."""
         try:
             self.store.load_state_dict(sd)
-        except (AssertionError, KeyError):
+        except (ValueError, KeyError):       # dense shapes (ValueError) / keys of dropped blocks (KeyError): prune, then load
             self.store.load_state_dict(slice_dense_state_dict(sd, self.cfg, self.blocks))
 
     # ------------------------------------------------------------------ nn.Module-ish surface

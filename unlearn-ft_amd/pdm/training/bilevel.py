@@ -33,7 +33,7 @@ class FusedAdamW:
         self.m = torch.zeros_like(store.master)
         self.v = torch.zeros_like(store.master)
         self.lr_dev = torch.zeros(1, device=dev)
-        self.bc_dev = torch.zeros(2, device=dev)
+        self.bc_dev = torch.ones(2, device=dev)      # 1, not 0: a launch() before the first prepare() (graph warm-up) must not divide by 0
         self.t = 0                     # optimiser steps taken
         self.sched_k = 0               # scheduler.step() calls (accelerate steps it `sched_mult`=W times per opt step)
         self.warmup = warmup_steps     # already multiplied by W by the caller (trainer.py:436-443)
@@ -76,13 +76,48 @@ class FusedAdamW:
         self.launch(grad_scale, zero_grad)
         return lr
 
+    # ---- checkpoint interchange: the files accelerator.save_state writes for a torch AdamW + LambdaLR pair
+    # (pdm/training/trainer.py:452-477: optimizer.bin / optimizer_1.bin, scheduler.bin / scheduler_1.bin)
     def state_dict(self):
-        return {"m": self.m.cpu(), "v": self.v.cpu(), "t": self.t, "sched_k": self.sched_k}
+        """`torch.optim.AdamW.state_dict()` layout: per-parameter {step, exp_avg, exp_avg_sq} in the reference's shapes
+        (diffusers names, pruned), keyed by the parameter's index in the reference module's `.parameters()` order."""
+        from ..models.unet.params import reference_param_order
+        s = self.store
+        order = reference_param_order(list(s.state_dict_names()))
+        state = {}
+        if self.t > 0:
+            m, v = s.state_dict(arena=self.m), s.state_dict(arena=self.v)
+            step = torch.tensor(float(self.t))
+            state = {i: {"step": step.clone(), "exp_avg": m[n], "exp_avg_sq": v[n]} for i, n in enumerate(order)}
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "foreach": None, "maximize": False, "capturable": False, "differentiable": False,
+                 "fused": None, "initial_lr": self.base_lr, "params": list(range(len(order)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.t, self.sched_k = sd["t"], sd["sched_k"]
+        from ..models.unet.params import reference_param_order
+        s = self.store
+        order = reference_param_order(list(s.state_dict_names()))
+        st = sd["state"]
+        if len(st) == 0:
+            self.m.zero_()
+            self.v.zero_()
+            self.t = 0
+            return
+        if len(st) != len(order):
+            raise ValueError(f"optimizer state has {len(st)} parameters, this model has {len(order)}")
+        s.load_state_dict({n: st[i]["exp_avg"] for i, n in enumerate(order)}, arena=self.m)
+        s.load_state_dict({n: st[i]["exp_avg_sq"] for i, n in enumerate(order)}, arena=self.v)
+        self.t = int(round(float(st[0]["step"])))
+
+    def scheduler_state_dict(self):
+        """`LambdaLR.state_dict()` layout of diffusers' constant_with_warmup scheduler (trainer.py:436-443)."""
+        lr = self.current_lr()
+        return {"base_lrs": [self.base_lr], "last_epoch": self.sched_k, "verbose": False, "_step_count": self.sched_k + 1,
+                "_get_lr_called_within_step": False, "_last_lr": [lr], "lr_lambdas": [None]}
+
+    def load_scheduler_state_dict(self, sd):
+        self.sched_k = int(sd["last_epoch"])
 
 
 class GradReducer:
@@ -188,6 +223,9 @@ class BilevelStepper:
 
     def _block_loss(self, acts_s, acts_t, B, weight, t_row0=0, seed=True):
         """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds."""
+        # when every layer of a block is dropped and it has no sampler, two hook keys hold the SAME activation (e.g. both
+        # resnets of down_blocks.3 dropped: acts['d3'] is acts['d2']): its gradient seed is the sum of both terms
+        seeded = set()
         for key in BLOCK_KEYS:
             a, b = acts_s[key], acts_t[key]
             M, C = a.t.shape
@@ -195,8 +233,11 @@ class BilevelStepper:
             n = len(BLOCK_KEYS) * M * C
             k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
             if seed and weight > 0:
-                a.g = torch.empty_like(a.t)
-                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
+                again = id(a) in seeded
+                if not again:
+                    a.g = torch.empty_like(a.t)
+                    seeded.add(id(a))
+                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, again)
 
     def _begin_wt_refresh(self):
         """The dgrad copies `wt` (W^T, flipped conv taps) of the weights the last optimiser step wrote are only read by the
@@ -228,8 +269,10 @@ class BilevelStepper:
         return self.reducer.finish()
 
     # ------------------------------------------------------------------ steps
-    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True):
+    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True, input_noise=None):
         """latents/noise [B,4,H,W] fp32 (latents already x scaling_factor), timesteps int64 [B], prompt_embeds [B,T,ctx].
+        input_noise: the perturbed noise of `input_perturbation` (trainer.py:2416-2417, 2427-2428) - it enters the forward
+        process, while the target is formed from the clean `noise`.
         Returns the device tensor [diff, dist, block, 0] (float64); total = w_diff*diff + w_block*block + w_dist*dist."""
         B, C, H, W = latents.shape
         w = self.w
@@ -237,6 +280,8 @@ class BilevelStepper:
         if backward:
             self._begin_wt_refresh()
         noisy, target = self._diffuse(latents, noise, timesteps, True)
+        if input_noise is not None:
+            noisy, _ = self._diffuse(latents, input_noise, timesteps, False)
         ehs = self._ehs2d(prompt_embeds)
         k.zero_(self.losses)
         cur = torch.cuda.current_stream()
@@ -302,6 +347,8 @@ class BilevelStepper:
         return self.losses
 
     def _block_loss_rows(self, acts_s, acts_t, B, weight, seed):
+        """Upper-step block term against the teacher's UNCONDITIONAL half (rows [M, 2M) of the 2B teacher batch)."""
+        seeded = set()
         for key in BLOCK_KEYS:
             a, b = acts_s[key], acts_t[key]
             M, C = a.t.shape
@@ -309,8 +356,11 @@ class BilevelStepper:
             n = len(BLOCK_KEYS) * M * C
             k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
             if seed:
-                a.g = torch.empty_like(a.t)
-                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, False)
+                again = id(a) in seeded
+                if not again:
+                    a.g = torch.empty_like(a.t)
+                    seeded.add(id(a))
+                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, again)
 
     def optimizer_step(self, upper=False, max_grad_norm=None):
         opt = self.upper_opt if upper else self.opt

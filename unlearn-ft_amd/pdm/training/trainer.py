@@ -88,12 +88,24 @@ class Trainer:
     def vae_factor(self):
         return 4 if _cfg(self.config, "tiny", False) else 8
 
+    def _allow_random(self, what, path):
+        """Random weights / a random arch vector stand in for missing files only when asked for (`--synthetic`, or
+        `model.prediction_model.random_init` like the reference's random_init path, unet_2d_conditional.py:2406-2408).
+        Otherwise a missing checkpoint is an error, as in the reference (every from_pretrained there raises)."""
+        if bool(_cfg(self.config, "synthetic", False)) or bool(_cfg(self.config, "model.prediction_model.random_init", False)):
+            return True
+        raise FileNotFoundError(
+            f"{what}: {path!r} is not a local directory / file (hub downloads are not available to this build); pass a local "
+            f"snapshot laid out like the hub's, or run with --synthetic / model.prediction_model.random_init for random weights")
+
     @property
     def vae(self):
         if getattr(self, "_vae", None) is None:
             from ..models.vae.autoencoder_kl import AutoencoderKL, VAEConfig
             root = _cfg(self.config, "pretrained_model_name_or_path")
             local = bool(root) and os.path.isdir(os.path.join(root, "vae"))
+            if not local:
+                self._allow_random("VAE", os.path.join(str(root), "vae"))
             vcfg = VAEConfig(block_out_channels=(32, 64, 64), layers_per_block=1) if _cfg(self.config, "tiny", False) else None
             self._vae = AutoencoderKL.from_pretrained(root if local else None, subfolder="vae", random_init=not local,
                                                       vae_config=vcfg, torch_dtype=self.weight_dtype, device=self.device)
@@ -106,6 +118,8 @@ class Trainer:
             from ..models.clip.text_encoder import CLIPTextModel, CLIPTextConfig
             root = _cfg(self.config, "pretrained_model_name_or_path")
             local = bool(root) and os.path.isdir(os.path.join(root, "text_encoder"))
+            if not local:
+                self._allow_random("text encoder", os.path.join(str(root), "text_encoder"))
             tcfg = None
             if _cfg(self.config, "tiny", False):
                 tcfg = CLIPTextConfig(vocab_size=1000, hidden_size=self.unet_config.cross_attention_dim, intermediate_size=256,
@@ -164,6 +178,7 @@ class Trainer:
         elif ckpt and os.path.exists(os.path.join(ckpt, "arch_vector.pt")):
             arch = torch.load(os.path.join(ckpt, "arch_vector.pt"), map_location="cpu")
         else:
+            self._allow_random("pruning checkpoint (quantizer_embeddings.pt / arch_vector.pt)", ckpt)
             res = int(_cfg(c, "model.prediction_model.resolution", 512)) // 8
             arch, ratio, _ = arch_vector_for_budget(ucfg, float(_cfg(c, "keep_ratio", 0.55)), hw=res)
             logger.info("no pruning checkpoint: random arch vector at MAC budget %.3f", ratio)
@@ -171,6 +186,8 @@ class Trainer:
         pm = _cfg(c, "model.prediction_model", {})
         root = _cfg(c, "pretrained_model_name_or_path")
         local = bool(root) and os.path.isdir(os.path.join(root, "unet"))
+        if not local:
+            self._allow_random("U-Net", os.path.join(str(root), "unet"))
         kw = dict(unet_config=ucfg, torch_dtype=self.weight_dtype, device=self.device,
                   down_block_types=pm.get("unet_down_blocks"), up_block_types=pm.get("unet_up_blocks"),
                   gated_ff=pm.get("gated_ff", True), ff_gate_width=pm.get("ff_gate_width", 32))
@@ -211,6 +228,14 @@ class Trainer:
             warmup_steps=int(o.get("lr_warmup_steps", 0)),
             upper_warmup_steps=int(o.get("upper_lr_warmup_steps", o.get("lr_warmup_steps", 0))), bilevel=self.bilevel)
         self.max_grad_norm = float(o["max_grad_norm"]) if o.get("clip_grad_norm") else None
+        sched = o.get("lr_scheduler", "constant_with_warmup")
+        if sched not in ("constant", "constant_with_warmup"):      # diffusers get_scheduler names (trainer.py:436-443)
+            raise ValueError(f"training.optim.lr_scheduler={sched!r} is not supported by this build (every shipped config "
+                             f"uses constant_with_warmup; 'constant' is the same with lr_warmup_steps 0)")
+        if sched == "constant":
+            self.stepper.opt.warmup = 0
+            if self.stepper.upper_opt is not None:
+                self.stepper.upper_opt.warmup = 0
 
     def init_dataloader(self, upper):
         c = self.config
@@ -238,14 +263,43 @@ class Trainer:
         off = float(_cfg(self.config, "model.prediction_model.noise_offset", 0.0) or 0.0)
         if off:
             noise = noise + off * torch.randn((lat.shape[0], lat.shape[1], 1, 1), device=self.device, generator=self.rng)
+        # trainer.py:2416-2417, 2427-2428: the forward process uses the perturbed noise, the target the clean one
+        pert = float(_cfg(self.config, "model.prediction_model.input_perturbation", 0.0) or 0.0)
+        self._input_noise = noise + pert * torch.randn(noise.shape, device=self.device, generator=self.rng) if pert else None
         mx = int(_cfg(self.config, "model.prediction_model.max_scheduler_steps", 1000) or 1000)
         t = torch.randint(0, mx, (lat.shape[0],), device=self.device, generator=self.rng).long()
         return lat, noise, t
 
-    def step(self, batch):
+    def step(self, batch, backward=True):
         lat, noise, t = self._sample(batch)
-        L = self.stepper.main_step(lat, noise, t, self._prompt_embeds(batch))
+        L = self.stepper.main_step(lat, noise, t, self._prompt_embeds(batch), backward=backward,
+                                   input_noise=self._input_noise)
         return self._tuple(L, upper=False)
+
+    # ---- trainer.py:2490-2541
+    @torch.no_grad()
+    def validate(self, eval_dataloader=None):
+        """`step()` without a backward over the evaluation batches, the four means reduced over the ranks (C4 of SURVEY
+        2.4: four scalar all-reduces) and logged under the reference's `validation/*` keys."""
+        loader = eval_dataloader if eval_dataloader is not None else getattr(self, "eval_dataloader", None)
+        if loader is None:
+            return None
+        tot = torch.zeros(4, device=self.device, dtype=torch.float64)
+        n = 0
+        for batch in loader:
+            n += 1                                            # the reference divides by len(eval_dataloader), skipped ones too
+            if self._is_empty(batch):
+                continue
+            tot += torch.stack(self.step(batch, backward=False)).double()
+        tot /= max(n, 1)
+        if self.world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            tot /= self.world
+        vals = tot.tolist()
+        rec = {"step": self.global_step, "validation/loss": vals[0], "validation/diffusion_loss": vals[1],
+               "validation/distillation_loss": vals[2], "validation/block_loss": vals[3]}
+        self._log(rec)
+        return rec
 
     def _tuple(self, L, upper):
         w = self.stepper.w
@@ -288,24 +342,37 @@ class Trainer:
                     (images.permute(0, 2, 3, 1) * 255).round().to(torch.uint8).cpu().numpy())
         return images
 
-    # ---- checkpointing (trainer.py:452-514, 2863-2869)
+    # ---- checkpointing (trainer.py:452-514, 2863-2869): the directory accelerator.save_state leaves behind
     def save_checkpoint(self):
+        """<logging_dir>/checkpoint-<step>/ = unet/ (diffusers safetensors, pruned shapes: the reference's save hook,
+        trainer.py:314-333), arch_vector.pt (:2867-2869), optimizer.bin + scheduler.bin (main AdamW / LambdaLR),
+        optimizer_1.bin + scheduler_1.bin (upper pair), random_states_<rank>.pkl - each in the layout torch / accelerate
+        write (torch.optim.AdamW.state_dict(), LambdaLR.state_dict(), accelerate's RNG dict) so that the reference's
+        accelerator.load_state can read what this build writes and vice versa."""
+        d = os.path.join(self.logging_dir, f"checkpoint-{self.global_step}")
+        os.makedirs(d, exist_ok=True)
+        import random
+        import numpy as np
+        rng = {"step": self.global_step, "random_state": random.getstate(), "numpy_random_seed": np.random.get_state(),
+               "torch_manual_seed": torch.get_rng_state(), "torch_cuda_manual_seed": torch.cuda.get_rng_state_all(),
+               "pdm_generator_state": self.rng.get_state().cpu()}        # this build draws from its own device generator
+        with open(os.path.join(d, f"random_states_{self.rank}.pkl"), "wb") as f:       # every rank writes its own
+            pickle.dump(rng, f)
         if self.rank != 0:
             return
-        d = os.path.join(self.logging_dir, f"checkpoint-{self.global_step}")
+        limit = _cfg(self.config, "training.logging.checkpoints_total_limit")
+        if limit:                                   # rotate BEFORE saving: at most limit-1 older ones stay (trainer.py:454-473)
+            cks = sorted((p for p in glob.glob(os.path.join(self.logging_dir, "checkpoint-*")) if p != d),
+                         key=lambda p: int(p.split("-")[-1]))
+            import shutil
+            for old in cks[:max(0, len(cks) - int(limit) + 1)]:
+                shutil.rmtree(old, ignore_errors=True)
         self.prediction_model.save_pretrained(os.path.join(d, "unet"))
         torch.save(self.arch_vector, os.path.join(d, "arch_vector.pt"))
-        torch.save(self.stepper.opt.state_dict(), os.path.join(d, "optimizer.bin"))
-        if self.stepper.upper_opt is not None:
-            torch.save(self.stepper.upper_opt.state_dict(), os.path.join(d, "optimizer_1.bin"))
-        with open(os.path.join(d, f"random_states_{self.rank}.pkl"), "wb") as f:
-            pickle.dump({"torch_cuda": self.rng.get_state().cpu()}, f)
-        limit = _cfg(self.config, "training.logging.checkpoints_total_limit")
-        if limit:
-            cks = sorted(glob.glob(os.path.join(self.logging_dir, "checkpoint-*")), key=lambda p: int(p.split("-")[-1]))
-            for old in cks[:-int(limit)]:
-                import shutil
-                shutil.rmtree(old, ignore_errors=True)
+        pairs = [("", self.stepper.opt)] + ([("_1", self.stepper.upper_opt)] if self.stepper.upper_opt is not None else [])
+        for suffix, opt in pairs:
+            torch.save(opt.state_dict(), os.path.join(d, f"optimizer{suffix}.bin"))
+            torch.save(opt.scheduler_state_dict(), os.path.join(d, f"scheduler{suffix}.bin"))
         logger.info("Saved state to %s", d)
 
     def load_checkpoint(self):
@@ -319,9 +386,20 @@ class Trainer:
             logger.info("Checkpoint %r does not exist. Starting a new training run.", r)
             return
         self.prediction_model.load_pretrained_dir(os.path.join(r, "unet"))
-        self.stepper.opt.load_state_dict(torch.load(os.path.join(r, "optimizer.bin")))
-        if self.stepper.upper_opt is not None and os.path.exists(os.path.join(r, "optimizer_1.bin")):
-            self.stepper.upper_opt.load_state_dict(torch.load(os.path.join(r, "optimizer_1.bin")))
+        pairs = [("", self.stepper.opt)] + ([("_1", self.stepper.upper_opt)] if self.stepper.upper_opt is not None else [])
+        for suffix, opt in pairs:
+            f = os.path.join(r, f"optimizer{suffix}.bin")
+            if os.path.exists(f):
+                opt.load_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+            f = os.path.join(r, f"scheduler{suffix}.bin")
+            if os.path.exists(f):
+                opt.load_scheduler_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+        f = os.path.join(r, f"random_states_{self.rank}.pkl")
+        if os.path.exists(f):
+            with open(f, "rb") as fh:
+                st = pickle.load(fh)
+            if "pdm_generator_state" in st:          # continue the noise / timestep stream where it stopped
+                self.rng.set_state(st["pdm_generator_state"])
         self.global_step = int(os.path.basename(r.rstrip("/")).split("-")[1])        # trainer.py:506
         logger.info("Resumed from %s at global step %d", r, self.global_step)
 
@@ -337,53 +415,78 @@ class UnetFineTuner(Trainer):
 
     def train(self):
         c = self.config
-        max_steps = int(_cfg(c, "training.max_train_steps", 100))
         ck_every = int(_cfg(c, "training.logging.checkpoint_steps", _cfg(c, "training.checkpoint_steps", 10000)))
+        val_every = int(_cfg(c, "training.validation_steps", 0) or 0)
         freq = int(_cfg(c, "training.upper_step_freq", 10))
+        accum = int(_cfg(c, "training.gradient_accumulation_steps", 1) or 1)
+        if accum != 1:
+            raise ValueError("gradient_accumulation_steps != 1 is not supported (every shipped config uses 1)")
+        # trainer.py:445-450 update_config_params / update_train_steps: max_train_steps, or num_train_epochs full passes
+        max_steps = _cfg(c, "training.max_train_steps")
+        try:
+            per_epoch = len(self.train_dataloader)
+        except TypeError:
+            per_epoch = None
+        if max_steps is None:
+            if per_epoch is None:
+                raise ValueError("training.max_train_steps is unset and the dataloader has no length")
+            max_steps = int(_cfg(c, "training.num_train_epochs", 1)) * per_epoch
+        max_steps = int(max_steps)
         self.load_checkpoint()
         upper_iter = iter(self.upper_dataloader) if self.bilevel else None
         pending = None
         t0 = time.time()
-        for batch in self.train_dataloader:
-            if self.global_step >= max_steps:
-                break
-            if self._is_empty(batch):                        # empty batch is skipped (trainer.py:2771-2772)
-                continue
-            loss = self.step(batch)
-            lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
-            rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
-            keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
-            vals = [torch.stack(loss)]
-            if self.bilevel and (self.global_step + 1) % freq == 0:          # trainer.py:2795-2816
-                try:
-                    ub = next(upper_iter)
-                except StopIteration:
-                    upper_iter = iter(self.upper_dataloader)
-                    ub = next(upper_iter)
-                up = self.upper_step(ub)
-                rec["finetuning/upper_prediction_model_lr"] = self.stepper.optimizer_step(upper=True,
-                                                                                          max_grad_norm=self.max_grad_norm)
-                keys += ("finetuning/upper_loss", "finetuning/upper_diffusion_loss",
-                         "finetuning/upper_distillation_loss", "finetuning/upper_block_loss")
-                vals.append(torch.stack(up))
-            host = torch.cat(vals).to("cpu", non_blocking=True)       # read back asynchronously, log one step late
-            if pending is not None:
-                self._flush(*pending)
-            pending = (rec, keys, host, torch.cuda.Event())
-            pending[3].record()
-            log_every = int(_cfg(c, "training.image_logging_steps", 0) or 0)
-            if log_every and self.prompt_dataloader is not None and self.global_step % log_every == 0:
-                self.generate_samples_from_prompts()
-            self.global_step += 1
-            if self.global_step % ck_every == 0:
-                self.save_checkpoint()
+        epoch = 0
+        while self.global_step < max_steps:          # for epoch in range(first_epoch, num_train_epochs), trainer.py:2769
+            stepped = False
+            for batch in self.train_dataloader:
+                if self.global_step >= max_steps:
+                    break
+                if self._is_empty(batch):                        # empty batch is skipped (trainer.py:2771-2772)
+                    continue
+                stepped = True
+                loss = self.step(batch)
+                lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
+                rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
+                keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
+                vals = [torch.stack(loss)]
+                if self.bilevel and (self.global_step + 1) % freq == 0:          # trainer.py:2795-2816
+                    try:
+                        ub = next(upper_iter)
+                    except StopIteration:
+                        upper_iter = iter(self.upper_dataloader)
+                        ub = next(upper_iter)
+                    up = self.upper_step(ub)
+                    rec["finetuning/upper_prediction_model_lr"] = self.stepper.optimizer_step(upper=True,
+                                                                                              max_grad_norm=self.max_grad_norm)
+                    keys += ("finetuning/upper_loss", "finetuning/upper_diffusion_loss",
+                             "finetuning/upper_distillation_loss", "finetuning/upper_block_loss")
+                    vals.append(torch.stack(up))
+                host = torch.cat(vals).to("cpu", non_blocking=True)       # read back asynchronously, log one step late
+                if pending is not None:
+                    self._flush(*pending)
+                pending = (rec, keys, host, torch.cuda.Event())
+                pending[3].record()
+                if val_every and self.global_step % val_every == 0:        # trainer.py:2848-2850
+                    self.validate()
+                log_every = int(_cfg(c, "training.image_logging_steps", 0) or 0)
+                if log_every and self.prompt_dataloader is not None and self.global_step % log_every == 0:
+                    self.generate_samples_from_prompts()
+                self.global_step += 1
+                if self.global_step % ck_every == 0:
+                    if self.world > 1:
+                        dist.barrier()
+                    self.save_checkpoint()
+            epoch += 1
+            if not stepped:
+                raise RuntimeError("the training dataloader yielded no usable batch in a whole epoch")
         if pending is not None:
             self._flush(*pending)
         torch.cuda.synchronize()
         if self.world > 1:
             dist.barrier()
         self.save_checkpoint()
-        logger.info("finished %d steps in %.1fs", self.global_step, time.time() - t0)
+        logger.info("finished %d steps (%d epochs) in %.1fs", self.global_step, epoch, time.time() - t0)
 
     def _flush(self, rec, keys, host, ev):
         ev.synchronize()
@@ -397,9 +500,30 @@ class BilevelUnetFineTuner(UnetFineTuner):
 
     def upper_step(self, batch):
         lat, noise, t = self._sample(batch)
+        if self._input_noise is not None:          # trainer.py:2917-2932: the upper step diffuses with the perturbed noise
+            noise = self._input_noise
         L = self.stepper.upper_step(lat, noise, t, self._prompt_embeds(batch), self._prompt_embeds(batch, empty=True))
         return self._tuple(L, upper=True)
 
 
+    def init_upper_dataset(self, dataset, preprocess_train=None):
+        """trainer.py:2634-2650: the upper (concept) dataset is the rows whose `style` column is in `upper_data.style`.
+        Dataset loading itself is host-side I/O outside this build: `dataset` is anything with
+        `column_names`, `filter` and `with_transform` (a `datasets.Dataset`), handed in by the caller."""
+        caption_column = _cfg(self.config, "upper_data.caption_column", "caption")
+        if caption_column not in dataset.column_names:
+            raise ValueError(f"--caption_column '{caption_column}' needs to be one of: {', '.join(dataset.column_names)}")
+        style = _cfg(self.config, "upper_data.style")
+        if style is not None:
+            dataset = dataset.filter(lambda s: s["style"] in style)        # `in`, as the reference: a string or a list of styles
+        return dataset.with_transform(preprocess_train) if preprocess_train is not None else dataset
+
+
 class NudityBilevelUnetFineTuner(BilevelUnetFineTuner):
-    """Same as BilevelUnetFineTuner; only the upper dataset selection differs (trainer.py:3004-3016)."""
+    """Same as BilevelUnetFineTuner; only the upper dataset selection differs (trainer.py:3004-3016): no `style` filter."""
+
+    def init_upper_dataset(self, dataset, preprocess_train=None):
+        caption_column = _cfg(self.config, "upper_data.caption_column", "caption")
+        if caption_column not in dataset.column_names:
+            raise ValueError(f"--caption_column '{caption_column}' needs to be one of: {', '.join(dataset.column_names)}")
+        return dataset.with_transform(preprocess_train) if preprocess_train is not None else dataset

@@ -26,6 +26,12 @@ def parse_args(argv=None):
     p.add_argument("--finetuning_ckpt_dir", type=str, default=None)
     p.add_argument("--expert_id", type=int, default=None)
     p.add_argument("--base_arch", action="store_true")
+    # accepted for command-line compatibility (pdm/utils/arg_utils.py:15-20, 51-54, 101-105, 120-121); the fine-tune /
+    # unlearn path reads none of them (CLIP scoring, EMA, pruning-ratio script and erasure baselines are out of scope)
+    p.add_argument("--clip_model_name_or_path", type=str, default="laion/CLIP-ViT-H-14-laion2B-s32B-b79K")
+    p.add_argument("--use_ema", action="store_true")
+    p.add_argument("--pruning_type", type=str, default="multi-expert", choices=["multi-expert", "single-expert"])
+    p.add_argument("--erasure_ckpt_path", type=str, default=None)
     # --- MI355X build additions
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic (latent, timestep, prompt-embed) batches")
     p.add_argument("--keep_ratio", type=float, default=0.55, help="MAC budget of the random arch vector in synthetic mode")
