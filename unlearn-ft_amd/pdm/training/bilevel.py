@@ -19,6 +19,7 @@ import torch.distributed as dist
 from .. import _pdmk as k
 from ..models.unet.spec import padc
 from ..utils.metric_utils import alphas_cumprod_sd, min_snr_weight_table
+from ..utils.roctx import phase
 
 BLOCK_KEYS = ("d0", "d1", "d2", "d3", "m", "u0", "u1", "u2", "u3")
 
@@ -57,9 +58,10 @@ class FusedAdamW:
         """Device-side part (graph-capturable): fused AdamW + refresh of the compute copies."""
         s = self.store
         fused = s.dtype == torch.bfloat16
-        k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
-                self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
-        s.refresh(w_is_fresh=fused, wt=not s.defer_wt)
+        with phase("adamw"):
+            k.adamw(s.master, s.grad, self.m, self.v, s.total, self.lr_dev, self.betas[0], self.betas[1], self.eps,
+                    self.wd, self.bc_dev, grad_scale, zero_grad, w_bf16=s.w if fused else None)
+            s.refresh(w_is_fresh=fused, wt=not s.defer_wt)
 
     def launch_range(self, lo, hi, grad_scale=1.0, zero_grad=True):
         """AdamW on arena slice [lo, hi) only (no refresh of the transposed copies): lets the update of layers whose
@@ -152,10 +154,11 @@ class GradReducer:
         g = self.store.grad[lo:hi]
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.stream):
+            with torch.cuda.stream(self.stream), phase("allreduce"):
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
         else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            with phase("allreduce"):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
     def finish(self):
         if self.world == 1:
@@ -247,7 +250,7 @@ class BilevelStepper:
             return
         cur = torch.cuda.current_stream()
         self.wt_stream.wait_stream(cur)
-        with torch.cuda.stream(self.wt_stream):
+        with torch.cuda.stream(self.wt_stream), phase("wt_refresh"):
             store.refresh_wt()
         self._wt_pending = True
 
@@ -279,35 +282,39 @@ class BilevelStepper:
         need_teacher = w["block"] > 0 or w["dist"] > 0
         if backward:
             self._begin_wt_refresh()
-        noisy, target = self._diffuse(latents, noise, timesteps, True)
-        if input_noise is not None:
-            noisy, _ = self._diffuse(latents, input_noise, timesteps, False)
-        ehs = self._ehs2d(prompt_embeds)
-        k.zero_(self.losses)
+        with phase("diffuse"):
+            noisy, target = self._diffuse(latents, noise, timesteps, True)
+            if input_noise is not None:
+                noisy, _ = self._diffuse(latents, input_noise, timesteps, False)
+            ehs = self._ehs2d(prompt_embeds)
+            k.zero_(self.losses)
         cur = torch.cuda.current_stream()
         ts = self.teacher_stream if self.teacher_stream is not None else cur
         if need_teacher:
             ts.wait_stream(cur)
-            with torch.cuda.stream(ts):
+            with torch.cuda.stream(ts), phase("fwd_teacher"):
                 pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
-        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        with phase("fwd_student"):
+            pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
         if need_teacher:
             cur.wait_stream(ts)
-        wb = self.snr_w[timesteps].contiguous()
-        HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
-        k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
-        if w["dist"] > 0:
-            k.mse_fwd(pred.t, pred_t.t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
-        if backward:
-            pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
-            k.mse_bwd(pred.t, target, wb, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["diff"] / n, False)
+        with phase("loss"):
+            wb = self.snr_w[timesteps].contiguous()
+            HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
+            k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
             if w["dist"] > 0:
-                k.mse_bwd(pred.t, pred_t.t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
-        if w["block"] > 0:
-            self._block_loss(acts, acts_t, B, w["block"], seed=backward)
+                k.mse_fwd(pred.t, pred_t.t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
+            if backward:
+                pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
+                k.mse_bwd(pred.t, target, wb, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["diff"] / n, False)
+                if w["dist"] > 0:
+                    k.mse_bwd(pred.t, pred_t.t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
+            if w["block"] > 0:
+                self._block_loss(acts, acts_t, B, w["block"], seed=backward)
         self.last_pred = pred
         if backward:
-            self._gscale = self._backward_and_reduce()
+            with phase("bwd"):
+                self._gscale = self._backward_and_reduce()
         return self.losses
 
     def upper_step(self, latents, noise, timesteps, prompt_embeds, empty_prompt_embeds, backward=True):
@@ -326,9 +333,10 @@ class BilevelStepper:
         cur = torch.cuda.current_stream()
         ts = self.teacher_stream if self.teacher_stream is not None else cur
         ts.wait_stream(cur)
-        with torch.cuda.stream(ts):
+        with torch.cuda.stream(ts), phase("fwd_teacher"):
             pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
-        pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
+        with phase("fwd_student"):
+            pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
         cur.wait_stream(ts)
         M = B * H * W
         e_c, e_u = pred_t.t[:M], pred_t.t[M:]
@@ -343,7 +351,8 @@ class BilevelStepper:
             self._block_loss_rows(acts, acts_t, B, w["up_block"], backward)
         self.last_pred = pred
         if backward:
-            self._gscale = self._backward_and_reduce()
+            with phase("bwd"):
+                self._gscale = self._backward_and_reduce()
         return self.losses
 
     def _block_loss_rows(self, acts_s, acts_t, B, weight, seed):
