@@ -258,8 +258,8 @@ def main():
             main_iter(i)
             if (i + 1) % a.upper_freq == 0:
                 upper_iter(i)
-        else:
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
+        else:      # the NEXT main batch is announced so that its (frozen) teacher forward runs beside this step
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=(u["lat"], u["noise"], u["t"], u["ehs"]))
             if (i + 1) % a.upper_freq == 0:
                 graphs.upper(u["lat"], u["noise"], u["t"], u["ehs"], empty)
 
@@ -296,12 +296,14 @@ def main():
         if world == 1:
             if graphs is not None:
                 d0 = data[0]
-                extras["ms_main_step"] = round(timed(lambda j: graphs.main(d0["lat"], d0["noise"], d0["t"], d0["ehs"]), 3) * 1e3, 2)
+                nx = (d0["lat"], d0["noise"], d0["t"], d0["ehs"])
+                extras["ms_main_step"] = round(timed(lambda j: graphs.main(*nx, nxt=nx), 3) * 1e3, 2)
                 extras["ms_upper_step"] = round(timed(lambda j: graphs.upper(d0["lat"], d0["noise"], d0["t"], d0["ehs"], empty), 2) * 1e3, 2)
                 st.defer_reduce = False
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
+        extras["teacher_prefetch"] = bool(graphs is not None and graphs.prefetch)
         if world == 1 and not a.no_vae and not a.tiny:
             # SURVEY 8f N1, NOT part of `value` (SURVEY 8d keeps the VAE off the timed path): what a pixel_values batch adds
             # in front of every step - vae.encode(pixels).latent_dist.sample() * 0.18215 (trainer.py:2405-2406)
@@ -431,8 +433,8 @@ def main():
         g2.capture(bilevel=True)
 
         def it2(i):
-            d = d2[i % 2]
-            g2.main(d["lat"], d["noise"], d["t"], d["ehs"])
+            d, n = d2[i % 2], d2[(i + 1) % 2]
+            g2.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=(n["lat"], n["noise"], n["t"], n["ehs"]))
             if (i + 1) % a.upper_freq == 0:
                 g2.upper(d["lat"], d["noise"], d["t"], d["ehs"], e2)
         for i in range(2):

@@ -61,7 +61,7 @@ def run(mode, world, rank, out=None):
         graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True)
         graphs.force_segments = True            # world 1 takes the multi-graph replay path too
         graphs.capture(bilevel=True)
-        assert len(graphs.g_main) == 3
+        assert len(graphs.g_main) == 3 + int(graphs.prefetch)     # + the cut between the loss heads and the backward
         assert torch.equal(store.master, init)  # capture restored the training state
     # ---- gradient of the first main step, reduced over the ranks, no optimiser
     d = data[ITERS]
@@ -69,6 +69,8 @@ def run(mode, world, rank, out=None):
         st.main_step(d["lat"], d["noise"], d["t"], d["ehs"])
         scale = st._gscale
     else:
+        if graphs.prefetch:
+            graphs.prime(d["lat"], d["noise"], d["t"], d["ehs"])
         graphs._load(d["lat"], d["noise"], d["t"], d["ehs"])
         graphs._replay_step(graphs.g_main, graphs.main_offs, None)
         scale = 1.0 / world
@@ -85,7 +87,8 @@ def run(mode, world, rank, out=None):
                 st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
                 st.optimizer_step(upper=True)
         else:
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
+            n = data[it + 1] if it + 1 < ITERS else None      # announce the next batch: its teacher forward runs beside this step
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=None if n is None else (n["lat"], n["noise"], n["t"], n["ehs"]))
             if it == UPPER_AT:
                 graphs.upper(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
     torch.cuda.synchronize()

@@ -231,7 +231,7 @@ def test_segmented_graph_replay_matches_eager(dev):
     ref = student.store.grad.clone()
     ref_loss = st.losses.clone()
     for nseg in (1, 4):
-        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False)
+        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False, prefetch=False)
         g.force_segments = nseg > 1
         g.capture(bilevel=False)
         assert len(g.g_main) == nseg, (len(g.g_main), g.main_offs)
@@ -279,6 +279,39 @@ def test_streamed_adamw_matches_step_then_optimizer(dev, forced):
         else:
             assert d.max().item() <= 4.2e-3 + 1e-2 * a.abs().max().item() * (what != "master"), (what, d.max().item())
         assert d.mean().item() <= 2e-3 * a.abs().mean().item() + 1e-6, (what, d.mean().item(), a.abs().mean().item())
+
+
+def test_teacher_prefetch_matches_in_step_teacher(dev):
+    """GraphedBilevel runs the frozen teacher's forward of batch i+1 as its own graph beside the student's step on batch i
+    and hands its outputs over through static buffers.  Four iterations on four different batches (with one upper step in
+    between, which must not disturb the hand-over) give the same losses and parameters as computing the teacher inside
+    every step - with the next batch announced (`nxt`), and without (every call primes)."""
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
+    g = torch.Generator().manual_seed(5)
+    batches = [tuple(x.cuda() for x in (torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g),
+                                        torch.randint(0, 1000, (2,), generator=g), torch.randn(2, 13, 64, generator=g)))
+               for _ in range(4)]
+    empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous().cuda()
+    results = []
+    for mode in ("in_step", "prefetch", "prime_only"):
+        ocfg, dense, psd, info, student, teacher = _setup(torch.float32)
+        st = BilevelStepper(student, teacher, lr=1e-4, upper_lr=1e-4, bilevel=True)
+        gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3, prefetch=(mode != "in_step"))
+        assert gr.prefetch == (mode != "in_step")
+        gr.capture(bilevel=True)
+        assert len(gr.g_main) == (2 if gr.prefetch else 1)
+        losses = []
+        for i, b in enumerate(batches):
+            gr.main(*b, nxt=batches[(i + 1) % 4] if mode == "prefetch" else None)
+            losses.append(st.losses.clone())
+            if i == 1:
+                gr.upper(*b, empty)
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses).cpu(), student.store.master.clone()))
+    for other in results[1:]:
+        assert torch.allclose(other[0], results[0][0], rtol=1e-5, atol=1e-9), (other[0], results[0][0])
+        d, dr = (other[1] - results[0][1]).abs().max().item(), results[0][1].abs().max().item()
+        assert d <= 1e-5 * dr + 8e-4, d          # Adam turns round-off-sized gradients into +-lr steps (see the DP test)
 
 
 @pytest.mark.parametrize("dn,tol", [("f32", 1e-3), ("bf16", 2e-2)])

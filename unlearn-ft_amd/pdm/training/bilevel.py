@@ -195,6 +195,7 @@ class BilevelStepper:
         self.reducer = GradReducer(student.store, bucket_mb)
         self.defer_reduce = False
         self.segment_cb = None
+        self.after_loss_cb = None      # GraphedBilevel: cut the captured graph between the loss heads and the backward
         self._gscale = 1.0 / world
         # the frozen teacher pass and the student forward are independent until the loss heads: they run on two HIP
         # streams (two parallel branches once captured in a hipGraph) so the small-grid layers of one fill the CUs the
@@ -272,10 +273,20 @@ class BilevelStepper:
         return self.reducer.finish()
 
     # ------------------------------------------------------------------ steps
-    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True, input_noise=None):
+    def teacher_pass(self, latents, noise, timesteps, prompt_embeds, input_noise=None):
+        """The frozen teacher's part of a main step on its own: forward diffusion + dense forward (trainer.py:2446-2448).
+        Returns (pred Act, {block key: Act}).  The teacher does not depend on the student, so GraphedBilevel runs this for
+        batch i+1 beside the student's backward pass of batch i and hands the result to main_step(teacher_out=...)."""
+        B, C, H, W = latents.shape
+        with phase("fwd_teacher"):
+            noisy, _ = self._diffuse(latents, noise if input_noise is None else input_noise, timesteps, False)
+            return self.teacher.forward_nhwc(noisy, timesteps, self._ehs2d(prompt_embeds), B, H, W, train=False)
+
+    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True, input_noise=None, teacher_out=None):
         """latents/noise [B,4,H,W] fp32 (latents already x scaling_factor), timesteps int64 [B], prompt_embeds [B,T,ctx].
         input_noise: the perturbed noise of `input_perturbation` (trainer.py:2416-2417, 2427-2428) - it enters the forward
         process, while the target is formed from the clean `noise`.
+        teacher_out: (pred, acts) of `teacher_pass` on the same inputs, computed earlier (the teacher is then not run here).
         Returns the device tensor [diff, dist, block, 0] (float64); total = w_diff*diff + w_block*block + w_dist*dist."""
         B, C, H, W = latents.shape
         w = self.w
@@ -290,13 +301,15 @@ class BilevelStepper:
             k.zero_(self.losses)
         cur = torch.cuda.current_stream()
         ts = self.teacher_stream if self.teacher_stream is not None else cur
-        if need_teacher:
+        if teacher_out is not None:
+            pred_t, acts_t = teacher_out
+        elif need_teacher:
             ts.wait_stream(cur)
             with torch.cuda.stream(ts), phase("fwd_teacher"):
                 pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
         with phase("fwd_student"):
             pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
-        if need_teacher:
+        if need_teacher and teacher_out is None:
             cur.wait_stream(ts)
         with phase("loss"):
             wb = self.snr_w[timesteps].contiguous()
@@ -312,6 +325,8 @@ class BilevelStepper:
             if w["block"] > 0:
                 self._block_loss(acts, acts_t, B, w["block"], seed=backward)
         self.last_pred = pred
+        if self.after_loss_cb is not None:
+            self.after_loss_cb()
         if backward:
             with phase("bwd"):
                 self._gscale = self._backward_and_reduce()
@@ -397,7 +412,7 @@ class GraphedBilevel:
        Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
        with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
 
-    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True):
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True, prefetch=None):
         self.st = stepper
         dev = stepper.dev
         self.lat = torch.zeros(B, C, H, W, device=dev)
@@ -405,6 +420,19 @@ class GraphedBilevel:
         self.t = torch.zeros(B, dtype=torch.int64, device=dev)
         self.ehs = torch.zeros(B, T, ctx, device=dev)
         self.empty = torch.zeros(B, T, ctx, device=dev)
+        # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=0 turns it off): the frozen teacher's forward of the NEXT main
+        # batch is its own graph, replayed on the teacher stream beside this iteration's student forward AND backward; its
+        # outputs are copied into static buffers once this iteration's loss heads have read the previous ones.  The
+        # teacher's ~10 ms then hide under the ~45 ms of student work instead of the ~12 ms student forward alone.
+        need_teacher = stepper.w["block"] > 0 or stepper.w["dist"] > 0
+        self.prefetch = (os.environ.get("PDMK_TEACHER_PREFETCH", "1") != "0" if prefetch is None else prefetch) and \
+            need_teacher and stepper.teacher_stream is not None
+        if self.prefetch:
+            self.n_lat, self.n_noise = torch.zeros_like(self.lat), torch.zeros_like(self.noise)
+            self.n_t, self.n_ehs = torch.zeros_like(self.t), torch.zeros_like(self.ehs)
+        self.g_teach = self.g_tcopy = None
+        self.T_out = None                    # (pred Act, {key: Act}) static teacher outputs read by the captured loss heads
+        self._primed = None                  # identity of the batch the static teacher outputs currently belong to
         self.g_main = self.g_opt = self.g_upper = self.g_uopt = None
         self.segments = segments
         self.force_segments = False          # tests: cut the backward into segments on a single rank as well
@@ -434,15 +462,27 @@ class GraphedBilevel:
         self.t.random_(0, 1000, generator=gen)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        if self.prefetch:
+            for buf, src in ((self.n_lat, self.lat), (self.n_noise, self.noise), (self.n_t, self.t), (self.n_ehs, self.ehs)):
+                buf.copy_(src)
         with torch.cuda.stream(side):
-            st.main_step(self.lat, self.noise, self.t, self.ehs)
+            if self.prefetch:                 # static teacher-output buffers, shaped by one eager pass
+                from ..models.unet.engine import Act
+                tp, ta = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
+                self.T_out = (Act(torch.empty_like(tp.t), rg=False), {k_: Act(torch.empty_like(a.t), rg=False) for k_, a in ta.items()})
+                self._copy_teacher(tp, ta)
+                del tp, ta
+            st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out)
             st.opt.launch(st._gscale)
             if bilevel:
                 st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
                 st.upper_opt.launch(st._gscale)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_main, self.main_offs = self._capture_step(lambda: st.main_step(self.lat, self.noise, self.t, self.ehs), st.opt)
+        if self.prefetch:
+            self._capture_teacher()
+        self.g_main, self.main_offs = self._capture_step(
+            lambda: st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out), st.opt, cut_after_loss=self.prefetch)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             st.opt.launch(st._gscale)
@@ -460,7 +500,51 @@ class GraphedBilevel:
         store.refresh()
         torch.cuda.synchronize()
 
-    def _capture_step(self, fn, opt):
+    def _copy_teacher(self, pred, acts):
+        dp, da = self.T_out
+        k.copy2d(pred.t, dp.t, pred.t.shape[0], pred.t.shape[1], pred.t.stride(0), dp.t.stride(0))
+        for key, a in acts.items():          # (the teacher is dense: no block is dropped, every key is its own activation)
+            k.copy2d(a.t, da[key].t, a.t.shape[0], a.t.shape[1], a.t.stride(0), da[key].t.stride(0))
+
+    @staticmethod
+    def _batch_id(lat, noise, t, ehs):
+        """Identity of a batch for the `nxt` hand-over: same tensors, not modified in place since."""
+        return tuple((x.data_ptr(), x._version) for x in (lat, noise, t, ehs))
+
+    def _capture_teacher(self):
+        """g_teach = forward diffusion + teacher forward of the NEXT batch (own memory pool: it runs concurrently with the
+        student's graphs); g_tcopy = its outputs -> the static buffers the captured loss heads read."""
+        st = self.st
+        gc.collect()
+        torch.cuda.synchronize()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(cap):
+                self.g_teach = torch.cuda.CUDAGraph()
+                self.g_teach.capture_begin(capture_error_mode="thread_local")
+                self._t_live = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
+                self.g_teach.capture_end()
+                self.g_tcopy = torch.cuda.CUDAGraph()
+                self.g_tcopy.capture_begin(capture_error_mode="thread_local")
+                self._copy_teacher(*self._t_live)
+                self.g_tcopy.capture_end()
+        finally:
+            if gc_was_on:
+                gc.enable()
+        torch.cuda.current_stream().wait_stream(cap)
+
+    def prime(self, lat, noise, t, ehs):
+        """Teacher outputs for a batch that was not announced as `next` by the previous main() (first iteration)."""
+        for buf, src in ((self.n_lat, lat), (self.n_noise, noise), (self.n_t, t), (self.n_ehs, ehs)):
+            buf.copy_(src)
+        self.g_teach.replay()
+        self.g_tcopy.replay()
+        self._primed = self._batch_id(lat, noise, t, ehs)
+
+    def _capture_step(self, fn, opt, cut_after_loss=False):
         """Captures one step (forward + loss heads + backward [+ streamed AdamW]).  The tape is cut at block boundaries into
         `self.segments` equal shares of the gradient arena (descending offsets).  world == 1: one graph; at every cut the
         AdamW of the finished share is forked onto `opt_stream` (a parallel branch of the graph).  world > 1: one graph per
@@ -495,6 +579,16 @@ class GraphedBilevel:
                     fork_adamw(off)
 
         st.segment_cb = seg_cb if nseg > 1 else None
+
+        def cut():       # teacher prefetch: graph boundary between the loss heads and the backward pass
+            if st._wt_pending:             # the dgrad-copy refresh forked at the top of the step joins inside this graph
+                torch.cuda.current_stream().wait_stream(st.wt_stream)
+                st._wt_pending = False
+            graphs[-1].capture_end()
+            offs.append(total)
+            graphs.append(torch.cuda.CUDAGraph())
+            graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
+        st.after_loss_cb = cut if cut_after_loss else None
         # like torch.cuda.graph(): collect garbage first, and keep the collector off while capturing - destroying an old
         # CUDAGraph (or freeing its pool) from a GC pass in the middle of a capture aborts the process
         gc.collect()
@@ -515,25 +609,47 @@ class GraphedBilevel:
                 gc.enable()
         offs.append(0)
         st.segment_cb = None
+        st.after_loss_cb = None
         torch.cuda.current_stream().wait_stream(cap_stream)
         return graphs, offs
 
-    def _replay_step(self, graphs, offs, opt=None):
-        """opt: the optimiser to stream (None = gradients only, the caller applies the optimiser)."""
+    def _replay_step(self, graphs, offs, opt=None, teach=False):
+        """opt: the optimiser to stream (None = gradients only, the caller applies the optimiser).
+        teach: graphs[0] ends after the loss heads; the next batch's teacher graph runs on the teacher stream beside ALL of
+        `graphs` and publishes its outputs once graphs[0] (the reader of the current ones) has been queued."""
         st = self.st
         store = st.student.store
+        cur = torch.cuda.current_stream()
+        ts = st.teacher_stream
+
+        def after_first():
+            if teach:
+                ts.wait_stream(cur)              # the loss heads of this iteration have read the static teacher outputs
+                with torch.cuda.stream(ts):
+                    self.g_tcopy.replay()
+        if teach:
+            ts.wait_stream(cur)                  # the next batch's inputs are loaded
+            with torch.cuda.stream(ts):
+                self.g_teach.replay()
         if st.world == 1:
-            for g in graphs:
+            multi_forced = self.force_segments
+            for i, g in enumerate(graphs):
                 g.replay()
-            if opt is not None and self.stream_opt and len(graphs) > 1:      # forced segments on one rank (tests)
+                if i == 0:
+                    after_first()
+            if opt is not None and self.stream_opt and multi_forced:          # forced segments on one rank (tests)
                 opt.launch_range(0, store.total, st._gscale)
                 store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
+            if teach:
+                cur.wait_stream(ts)
             return
         red = st.reducer
         red.begin()
         done = store.total                       # AdamW has been issued for [done, total)
-        for g, off in zip(graphs, offs):
+        for i, (g, off) in enumerate(zip(graphs, offs)):
             g.replay()
+            if i == 0:
+                after_first()
             red.ready_down_to(off)               # comm stream waits for the segment just queued, then all-reduces its share
             if opt is not None and self.stream_opt and red.stream is not None and red.next_hi < done:
                 with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind it
@@ -543,11 +659,27 @@ class GraphedBilevel:
         if opt is not None and self.stream_opt:
             opt.launch_range(0, done, st._gscale)
             store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
+        if teach:
+            cur.wait_stream(ts)
 
-    def main(self, lat, noise, t, ehs):
+    def main(self, lat, noise, t, ehs, nxt=None):
+        """One main step + its AdamW.  nxt = (lat, noise, t, ehs) of the NEXT main() call (teacher prefetch): its teacher
+        forward runs beside this step; without it (or on the first call) the teacher outputs of THIS batch are computed
+        up front on the teacher stream (`prime`)."""
         lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches inside the step
         self._load(lat, noise, t, ehs)
-        self._replay_step(self.g_main, self.main_offs, self.st.opt)
+        teach = False
+        if self.prefetch:
+            if self._primed != self._batch_id(lat, noise, t, ehs):
+                self.prime(lat, noise, t, ehs)
+            if nxt is not None:
+                for buf, src in ((self.n_lat, nxt[0]), (self.n_noise, nxt[1]), (self.n_t, nxt[2]), (self.n_ehs, nxt[3])):
+                    buf.copy_(src)
+                teach = True
+                self._primed = self._batch_id(*nxt)
+            else:
+                self._primed = None
+        self._replay_step(self.g_main, self.main_offs, self.st.opt, teach=teach)
         if not self.stream_opt:
             self.g_opt.replay()
         return lr
