@@ -50,8 +50,8 @@ def cpu_baseline(budget, latent, tiny, full=False):
     weights or datasets), not the target.  Protocol = BASELINE.md 3: main step = dense teacher fwd + budget student
     fwd/bwd + 3 loss heads + AdamW; warm-up steps, then the MEDIAN of the timed ones; one upper step (2 teacher fwds +
     student fwd/bwd + upper AdamW) for the bilevel blend 10*B / (10*t_main + t_upper).
-    Default (bounded so that the whole bench stays within minutes): 1 warm-up + 3 timed main steps + 1 upper step at all
-    cores.  --cpu_baseline_full: 3 warm-up + 5 timed at all cores AND at 8 threads."""
+    Default (bounded so that the whole bench stays within minutes): 1 warm-up + 2 timed main steps + 1 upper step at all
+    cores (~2 minutes).  --cpu_baseline_full: 3 warm-up + 5 timed at all cores AND at 8 threads (profiles/ keeps one)."""
     import platform
     import statistics
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -106,7 +106,7 @@ def cpu_baseline(budget, latent, tiny, full=False):
         return {"threads": threads, "warmup": warm, "timed": timed, "main_step_s_median": round(tm, 3),
                 "main_step_s_all": [round(x, 3) for x in ts], "upper_step_s": round(tu, 3),
                 "images_per_s_main": round(1.0 / tm, 5), "images_per_s_bilevel": round(10.0 / (10.0 * tm + tu), 5)}
-    first = run(all_cores, 3 if full else 1, 5 if full else 3)
+    first = run(all_cores, 3 if full else 1, 5 if full else 2)
     out = {"value": first["images_per_s_bilevel"], "unit": "images/s", "cores": all_cores, "kind": "port",
            "cpu_model": model,
            "sample": f"bilevel blend 10/(10 t_main + t_upper) of the pure-torch CPU oracle at B=1, {latent}x{latent} latent, fp32, "
