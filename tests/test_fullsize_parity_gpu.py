@@ -112,7 +112,7 @@ def _oracle(kind, budget, hw=64, grads=True):
             out = ostep.upper_step_loss((P, info), tch, ocfg, ostep.alphas_cumprod(), lat, noise, t, ehs, empty)
         if grads:
             out[0].backward()
-    res = (tuple(float(x) for x in out[:4]), {n: p.grad for n, p in P.items()} if grads else None, av)
+    res = (tuple(float(x.detach()) for x in out[:4]), {n: p.grad for n, p in P.items()} if grads else None, av)
     _CACHE[key] = res
     return res
 

@@ -324,45 +324,68 @@ def test_bilevel_loss_curve_matches_oracle(dev, dn, tol):
     rounding is 2^-9 = 2e-3 relative and a loss is a mean of squared O(1) differences behind ~100 rounded layers, so the
     curve cannot track an fp32 reference to 1e-3; what it must not do is DRIFT: the bound is the same at iteration 9 as
     at iteration 1 (fp32 master weights, so rounding does not accumulate in the parameters)."""
-    from pdm_ref import step as ostep, weights as oweights
     from pdm.training.bilevel import BilevelStepper
     ocfg, dense, psd, info, student, teacher = _setup(torch.float32 if dn == "f32" else torch.bfloat16, drop_depth=(1, 9))
-    ac = ostep.alphas_cumprod()
     lr, ulr = 2e-5, 5e-5
+    ref_curve = _oracle_curve(ocfg, dense, psd, info, lr, ulr)
     st = BilevelStepper(student, teacher, lr=lr, upper_lr=ulr, bilevel=True)
-    P = {k_: v.clone() for k_, v in psd.items()}
-    mom = [({k_: torch.zeros_like(v) for k_, v in P.items()}, {k_: torch.zeros_like(v) for k_, v in P.items()}) for _ in range(2)]
-    tinfo = oweights.dense_info(ocfg)
-    steps = [0, 0]
-    curve, ref_curve = [], []
-    g = torch.Generator().manual_seed(7)
-    for it in range(9):
-        lat, noise = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g)
-        t = torch.randint(0, 1000, (2,), generator=g)
-        ehs = torch.randn(2, 13, 64, generator=g)
-        empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous()
-        phases = [("main", 0)] + ([("upper", 1)] if (it + 1) % 3 == 0 else [])
-        for name, oi in phases:
-            Pg = {k_: v.clone().requires_grad_(True) for k_, v in P.items()}
+    curve = []
+    for it, (lat, noise, t, ehs, empty) in enumerate(_curve_inputs()):
+        for name in ["main"] + (["upper"] if (it + 1) % 3 == 0 else []):
             if name == "main":
-                loss = ostep.main_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs)[0]
                 L = st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
             else:
-                loss = ostep.upper_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, empty)[0]
                 L = st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda())
-            loss.backward()
-            steps[oi] += 1
-            ostep.adamw_step(P, {k_: v.grad for k_, v in Pg.items()}, mom[oi][0], mom[oi][1], steps[oi], lr if oi == 0 else ulr)
-            st.optimizer_step(upper=bool(oi))
-            curve.append((name, st.total(L, upper=bool(oi))[0]))
-            ref_curve.append(loss.item())
-    assert len(curve) == 12
+            st.optimizer_step(upper=name == "upper")
+            curve.append((name, st.total(L, upper=name == "upper")[0]))
+    assert len(curve) == 12 == len(ref_curve)
     worst = max(abs(got - ref) / max(abs(ref), 1e-6) for (_, got), ref in zip(curve, ref_curve))
     assert worst <= tol, [(n, round(got, 6), round(ref, 6)) for (n, got), ref in zip(curve, ref_curve)]
     # the curves must actually move (the optimisers are live): last main loss differs from a frozen-weights evaluation
     new = student.state_dict()
     drift = max((new[n] - psd[n]).abs().max().item() for n in psd)
     assert drift > 5e-5
+
+
+def _curve_inputs():
+    g = torch.Generator().manual_seed(7)
+    out = []
+    for _ in range(9):
+        lat, noise = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g)
+        t = torch.randint(0, 1000, (2,), generator=g)
+        ehs = torch.randn(2, 13, 64, generator=g)
+        empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous()
+        out.append((lat, noise, t, ehs, empty))
+    return out
+
+
+_CURVE = {}
+
+
+def _oracle_curve(ocfg, dense, psd, info, lr, ulr):
+    """The same 9-iteration bilevel loop on the CPU oracle (autograd + its AdamW restatement); computed once per session
+    (it does not depend on the engine dtype under test)."""
+    if "ref" in _CURVE:
+        return _CURVE["ref"]
+    from pdm_ref import step as ostep, weights as oweights
+    ac = ostep.alphas_cumprod()
+    P = {k_: v.clone() for k_, v in psd.items()}
+    mom = [({k_: torch.zeros_like(v) for k_, v in P.items()}, {k_: torch.zeros_like(v) for k_, v in P.items()}) for _ in range(2)]
+    tinfo = oweights.dense_info(ocfg)
+    steps, ref = [0, 0], []
+    for it, (lat, noise, t, ehs, empty) in enumerate(_curve_inputs()):
+        for name, oi in [("main", 0)] + ([("upper", 1)] if (it + 1) % 3 == 0 else []):
+            Pg = {k_: v.clone().requires_grad_(True) for k_, v in P.items()}
+            if name == "main":
+                loss = ostep.main_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs)[0]
+            else:
+                loss = ostep.upper_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, empty)[0]
+            loss.backward()
+            steps[oi] += 1
+            ostep.adamw_step(P, {k_: v.grad for k_, v in Pg.items()}, mom[oi][0], mom[oi][1], steps[oi], lr if oi == 0 else ulr)
+            ref.append(loss.item())
+    _CURVE["ref"] = ref
+    return ref
 
 
 def test_deferred_wt_refresh_is_complete_before_backward(dev):
