@@ -85,7 +85,19 @@ typedef struct pdmk_gemm_args {
     int32_t splitk;
     float alpha;
     int32_t ldrv;        /* row stride of rowvec in floats; 0 = N (a column slice of one batched time-embedding projection) */
+    int32_t epilogue;    /* PDMK_EPI_NONE | PDMK_EPI_GEGLU */
+    int32_t ldc2;        /* row stride of C2 */
+    void* C2;            /* PDMK_EPI_GEGLU: optional [M, N] copy of the pre-activation (what the backward needs), or NULL */
 } pdmk_gemm_args;
+
+/* PDMK_EPI_GEGLU (GEGLUGated.forward, pdm/models/unet/blocks.py:44-59 = Linear -> chunk -> hidden * gelu_erf(gate)), fused
+ * into the projection's epilogue: the N GEMM columns hold (hidden, gate) INTERLEAVED in blocks of 8 - columns
+ * [16q, 16q+8) = hidden features 8q..8q+7, [16q+8, 16q+16) = their gates (the host packs the weight rows that way) - and
+ * C is [M, N/2]: C[m, 8q+e] = (x + bias)[16q+e] * gelu((x + bias)[16q+8+e]), both rounded to `dtype` first (bit-identical
+ * to storing the projection and running pdmk_geglu_fwd on it).  bf16 only, N % 16 == 0, ldc / ldc2 % 8 == 0, splitk 1,
+ * no residual / rowvec / accumulate; served by the LDS-DMA ring kernels only (-2 otherwise: use the two-pass form). */
+#define PDMK_EPI_NONE 0
+#define PDMK_EPI_GEGLU 1
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
 /* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller
@@ -171,10 +183,12 @@ int64_t pdmk_attn_bwd_workspace_bytes(int B, int H, int Nq, int Nk);
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise / reduction family.
  */
-/* GEGLU (blocks.py:44-59, exact erf GELU): x [M, 2F] (ld) = [h | g]  ->  y[M,F] = h * gelu(g). */
-int pdmk_geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int dtype, pdmk_stream stream);
-int pdmk_geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx, int dtype,
-                   pdmk_stream stream);
+/* GEGLU (blocks.py:44-59, exact erf GELU): x [M, 2F] (ld) -> y[M,F] = h * gelu(g).  layout 0: x = [h | g] halves;
+ * layout 1: h and g interleaved in blocks of 8 columns as PDMK_EPI_GEGLU consumes them (F % 8 == 0).  bwd writes dx in
+ * the same layout. */
+int pdmk_geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int layout, int dtype, pdmk_stream stream);
+int pdmk_geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx, int layout,
+                   int dtype, pdmk_stream stream);
 /* y = silu(x) over n contiguous elements (time-embedding MLP, blocks.py:336); bwd: dx = dy * silu'(x). */
 int pdmk_silu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream stream);
 int pdmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, pdmk_stream stream);

@@ -417,7 +417,7 @@ def force_cfg():
         os.environ.pop(var, None)
 
 
-@pytest.mark.parametrize("cand", list(range(13)))
+@pytest.mark.parametrize("cand", list(range(13)) + [17, 18, 19])
 def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
     """Every fwd/dgrad candidate of the plan cache gives the same linear + 3x3-conv results (ragged M/N/K tails, K not
     a multiple of the K-step, stride-2 / upsample / transposed gathers, split-K with fp32 atomics)."""
@@ -571,3 +571,68 @@ def test_halo_conv_candidates(dev, force_cfg, cand):
             k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci),
                    out_f32=True, splitk=sk)
         close(y, ref, 2e-2, f"halo conv B{Bn} {Hs}x{Hs} {Ci}->{Co} sk{sk}")
+
+
+def _interleave8(h, g):
+    """[.., F] hidden and gate -> [.., 2F] with (hidden, gate) interleaved in blocks of 8 columns (PDMK_EPI_GEGLU layout)."""
+    F_ = h.shape[-1]
+    return torch.stack([h.reshape(*h.shape[:-1], F_ // 8, 8), g.reshape(*g.shape[:-1], F_ // 8, 8)], dim=-2).reshape(*h.shape[:-1], 2 * F_)
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_geglu_interleaved_layout(dev, dn):
+    """layout 1 of pdmk_geglu_fwd / _bwd: hidden / gate interleaved in blocks of 8 columns, strided rows."""
+    from pdm import _pdmk as k
+    torch.manual_seed(21)
+    dt = DT[dn]
+    M, Fd, ld = 37, 48, 104
+    h, g = rnd((M, Fd), dev, dt), rnd((M, Fd), dev, dt)
+    x = torch.zeros(M, ld, device=dev, dtype=dt)
+    x[:, :2 * Fd] = _interleave8(h, g)
+    y = torch.zeros(M, Fd, device=dev, dtype=dt)
+    k.geglu_fwd(x, y, M, Fd, ld, Fd, layout=1)
+    hr, gr = h.float().requires_grad_(True), g.float().requires_grad_(True)
+    ref = hr * F.gelu(gr)
+    close(y, ref, TOL[dn], "geglu layout 1")
+    dy = rnd((M, Fd), dev, dt)
+    gh, gg = torch.autograd.grad(ref, [hr, gr], dy.float())
+    dx = torch.zeros(M, ld, device=dev, dtype=dt)
+    k.geglu_bwd(x, dy, dx, M, Fd, ld, Fd, ld, layout=1)
+    close(dx[:, :2 * Fd], _interleave8(gh, gg), TOL[dn] * 2, "geglu bwd layout 1")
+    assert float(dx[:, 2 * Fd:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cand", [1, 4, 6, 8, 9, 10, 12, 17, 18, 19, -1])
+def test_gemm_fused_geglu_epilogue(dev, force_cfg, cand):
+    """PDMK_EPI_GEGLU: hidden * gelu(gate) formed in the projection's epilogue equals - bit for bit - the projection stored
+    in bf16 followed by pdmk_geglu_fwd(layout 1), for every ring tile shape (ragged M, N tails of 16, K tail), with and
+    without the pre-activation copy; the K-step-32 kernels have no such epilogue (status -2 -> False)."""
+    from pdm import _pdmk as k
+    if cand >= 0:
+        force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(22)
+    dt = torch.bfloat16
+    for M, N, K in ((515, 352, 608), (200, 48, 96), (64, 32, 32), (1000, 1296, 160)):
+        A, B = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5)
+        bias = torch.randn(N, device=dev)
+        two = torch.zeros(M, N, device=dev, dtype=dt)
+        k.gemm(A, B, two, M, N, K, K, K, N, bias=bias)
+        ref = torch.zeros(M, N // 2, device=dev, dtype=dt)
+        k.geglu_fwd(two, ref, M, N // 2, N, N // 2, layout=1)
+        for keep in (True, False):
+            gl = torch.full((M, N // 2 + 8), 5.0, device=dev, dtype=dt)[:, :N // 2]      # strided output rows
+            f = torch.full((M, N), 7.0, device=dev, dtype=dt) if keep else None
+            assert k.gemm_geglu(A, B, gl, f, M, N, K, K, K, bias=bias)
+            assert torch.equal(gl, ref), (M, N, K, keep, (gl.float() - ref.float()).abs().max().item())
+            if keep:
+                assert torch.equal(f, two)
+        # against fp32 math on the same inputs
+        pre = (A.float() @ B.float().t() + bias).to(dt).float()
+        hg = pre.reshape(M, N // 16, 2, 8)
+        close(ref, (hg[:, :, 0] * F.gelu(hg[:, :, 1])).reshape(M, N // 2), 2e-2, "fused geglu vs fp32")
+    os_environ = __import__("os").environ
+    os_environ["PDMK_RING_CFG"] = "0"
+    gl = torch.zeros(64, 16, device=dev, dtype=dt)
+    assert k.gemm_geglu(rnd((64, 32), dev, dt), rnd((32, 32), dev, dt), gl, None, 64, 32, 32, 32, 32) in (True, False)
+    with pytest.raises(k.PdmkError):        # N not a multiple of 16
+        k.gemm_geglu(rnd((64, 32), dev, dt), rnd((24, 32), dev, dt), gl, None, 64, 24, 32, 32, 32)

@@ -11,16 +11,18 @@ inline int grid_for(long nwork, int cap = 4096) { return (int)max(1L, min((long)
 
 // ------------------------------------------------------------------------------------------------ GEGLU
 template <typename T>
-__global__ void geglu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long M, int F, int ldx, int ldy) {
+// layout 1: hidden / gate interleaved in blocks of 8 columns (hidden feature c at 16 (c / 8) + c % 8, its gate 8 further)
+__global__ void geglu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long M, int F, int ldx, int ldy, int layout) {
     constexpr int V = Vec<T>::N;
     const int fc = F / V;
     const long total = M * fc;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const long m = i / fc;
         const int c = (int)(i - m * fc) * V;
+        const int ho = layout ? ((c >> 3) << 4) + (c & 7) : c, go = layout ? ho + 8 : F + c;
         float h[V], g[V];
-        Vec<T>::load(x + m * ldx + c, h);
-        Vec<T>::load(x + m * ldx + F + c, g);
+        Vec<T>::load(x + m * ldx + ho, h);
+        Vec<T>::load(x + m * ldx + go, g);
 #pragma unroll
         for (int e = 0; e < V; ++e) h[e] *= gelu_f(g[e]);
         Vec<T>::store(y + m * ldy + c, h);
@@ -28,40 +30,41 @@ __global__ void geglu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, lon
 }
 template <typename T>
 __global__ void geglu_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long M, int F,
-                                 int ldx, int lddy, int lddx) {
+                                 int ldx, int lddy, int lddx, int layout) {
     constexpr int V = Vec<T>::N;
     const int fc = F / V;
     const long total = M * fc;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const long m = i / fc;
         const int c = (int)(i - m * fc) * V;
+        const int ho = layout ? ((c >> 3) << 4) + (c & 7) : c, go = layout ? ho + 8 : F + c;
         float h[V], g[V], d[V], dh[V], dg[V];
-        Vec<T>::load(x + m * ldx + c, h);
-        Vec<T>::load(x + m * ldx + F + c, g);
+        Vec<T>::load(x + m * ldx + ho, h);
+        Vec<T>::load(x + m * ldx + go, g);
         Vec<T>::load(dy + m * lddy + c, d);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             dh[e] = d[e] * gelu_f(g[e]);
             dg[e] = d[e] * h[e] * gelu_grad_f(g[e]);
         }
-        Vec<T>::store(dx + m * lddx + c, dh);
-        Vec<T>::store(dx + m * lddx + F + c, dg);
+        Vec<T>::store(dx + m * lddx + ho, dh);
+        Vec<T>::store(dx + m * lddx + go, dg);
     }
 }
-template <typename T> int geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, hipStream_t st) {
+template <typename T> int geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int layout, hipStream_t st) {
     constexpr int V = Vec<T>::N;
-    if (F % V || ldx % V || ldy % V) return -1;
+    if (F % V || ldx % V || ldy % V || (layout && (F % 8))) return -1;
     hipLaunchKernelGGL(geglu_fwd_kernel<T>, dim3(grid_for((long)M * F / V)), dim3(NT), 0, st, (const T*)x, (T*)y,
-                       (long)M, F, ldx, ldy);
+                       (long)M, F, ldx, ldy, layout);
     PDMK_CHECK_LAUNCH();
     return 0;
 }
 template <typename T>
-int geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx, hipStream_t st) {
+int geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx, int layout, hipStream_t st) {
     constexpr int V = Vec<T>::N;
-    if (F % V || ldx % V || lddy % V || lddx % V) return -1;
+    if (F % V || ldx % V || lddy % V || lddx % V || (layout && (F % 8))) return -1;
     hipLaunchKernelGGL(geglu_bwd_kernel<T>, dim3(grid_for((long)M * F / V)), dim3(NT), 0, st, (const T*)x,
-                       (const T*)dy, (T*)dx, (long)M, F, ldx, lddy, lddx);
+                       (const T*)dy, (T*)dx, (long)M, F, ldx, lddy, lddx, layout);
     PDMK_CHECK_LAUNCH();
     return 0;
 }
@@ -493,14 +496,14 @@ __global__ void sumsq_kernel(const float* __restrict__ x, long n, double* __rest
 
 }  // namespace
 
-extern "C" int pdmk_geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int dtype, pdmk_stream s) {
+extern "C" int pdmk_geglu_fwd(const void* x, void* y, int M, int F, int ldx, int ldy, int layout, int dtype, pdmk_stream s) {
     if (!x || !y || M <= 0 || F <= 0) return -1;
-    PDMK_DISPATCH(dtype, geglu_fwd, x, y, M, F, ldx, ldy, (hipStream_t)s);
+    PDMK_DISPATCH(dtype, geglu_fwd, x, y, M, F, ldx, ldy, layout, (hipStream_t)s);
 }
 extern "C" int pdmk_geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, int lddy, int lddx,
-                              int dtype, pdmk_stream s) {
+                              int layout, int dtype, pdmk_stream s) {
     if (!x || !dy || !dx || M <= 0 || F <= 0) return -1;
-    PDMK_DISPATCH(dtype, geglu_bwd, x, dy, dx, M, F, ldx, lddy, lddx, (hipStream_t)s);
+    PDMK_DISPATCH(dtype, geglu_bwd, x, dy, dx, M, F, ldx, lddy, lddx, layout, (hipStream_t)s);
 }
 extern "C" int pdmk_silu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream s) {
     if (!x || !y || n <= 0) return -1;

@@ -562,8 +562,8 @@ size_t g_scratch_bytes = 0;
 PlanKey make_key(const pdmk_gemm_args& g, int sk) {
     PlanKey k;
     const bool cv = g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV;
-    const int v[10] = {g.M, g.N, g.K, g.a_mode, g.b_mode, cv ? g.conv_mode : 0, cv ? g.conv_hi : 0, cv ? g.conv_wi : 0,
-                       cv ? g.conv_ci : 0, sk};
+    const int v[10] = {g.M, g.N, g.K, g.a_mode, g.b_mode, cv ? g.conv_mode : 100 * g.epilogue, cv ? g.conv_hi : 0,
+                       cv ? g.conv_wi : 0, cv ? g.conv_ci : 0, sk};
     memcpy(k.v, v, sizeof v);
     return k;
 }
@@ -661,6 +661,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     a.accumulate = 0;
     a.splitk = sk;
     a.ldc = g.N;
+    a.C2 = nullptr;                                  // tuning writes into scratch: the optional second output is left out
     if (a.colsum_out)
         a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(out2) + out_bytes);      // bias gradient -> scratch
     if (g.a_mode == PDMK_A_COLK) a.C = ws;                                      // wgrad: fp32, atomics for sk > 1
@@ -669,7 +670,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     int best = -1;
     float bt = 1e30f;
     const int ncand = 1 + (g.a_mode == PDMK_A_COLK ? pdmk_wgrad_ring_num_configs() : pdmk_gemm_ring_num_configs());
-    for (int id = 0; id < ncand; ++id) {
+    for (int id = g.epilogue ? 1 : 0; id < ncand; ++id) {        // fused epilogues live in the ring kernels only
         const float t = time_candidate(a, st, id, ws, out2, e0, e1);
         if (t < bt) { bt = t; best = id; }
     }
@@ -744,12 +745,21 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.accumulate == 2 && (g.splitk <= 1 || !(g.out_f32 || g.dtype == PDMK_F32) || g.bias || g.rowvec || g.R)) return -1;
     if (g.accumulate < 0 || g.accumulate > 2) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
+    if (g.epilogue != PDMK_EPI_NONE) {
+        if (g.epilogue != PDMK_EPI_GEGLU) return -2;
+        if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_ROWK || g.b_mode != PDMK_B_ROWK || g.out_f32) return -2;
+        if ((g.N % 16) || (g.ldc % 8) || (g.C2 && (g.ldc2 % 8)) || g.splitk > 1 || g.accumulate || g.R || g.rowvec ||
+            g.alpha != 1.0f || (g.K % 8))
+            return -1;
+        if (!ring_mode()) return -2;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_last_candidate = 0;
     if (!(ring_eligible(g) && (g.K % 8) == 0) && !wgrad_eligible(g)) return launch_legacy(g, st);
-    if (g.a_mode == PDMK_A_COLK ? forced_wcfg() >= 0 : forced_cfg() >= 0) {
+    if ((g.a_mode == PDMK_A_COLK ? forced_wcfg() >= 0 : forced_cfg() >= 0) && !(g.epilogue && forced_cfg() == 0)) {
         const int rc = launch_candidate(g, st, g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
         g_last_candidate = rc == 1 ? 0 : (g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
+        if (g.epilogue && rc == 1) return -2;
         return rc == 1 ? launch_legacy(g, st) : rc;
     }
     const int sk = g.splitk > 1 ? g.splitk : 1;
@@ -768,7 +778,9 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
             plan_file_append('c', key, id);
         } else id = heuristic_cfg(g);                   // not cached: a later eager call may still tune it
     }
+    if (g.epilogue && id <= 0) id = 1 + pdmk_gemm_ring_pick(g);
     const int rc = launch_candidate(g, st, id);
+    if (g.epilogue && rc == 1) return -2;               // no ring kernel takes this shape: the caller uses the two-pass form
     g_last_candidate = rc == 1 ? 0 : id;
     return rc == 1 ? launch_legacy(g, st) : rc;
 }
@@ -795,7 +807,7 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     *splitk_out = 1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
-    if (g.N & 3) return 0;
+    if ((g.N & 3) || g.epilogue) return 0;           // fused epilogues are never split
     const bool wg = wgrad_eligible(g);
     if (g.a_mode == PDMK_A_COLK && !wg) {
         *splitk_out = heuristic_wgrad_sk(g);
@@ -821,7 +833,7 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
         if (wg) {      // weight gradients: the reduction (pixels) is the long dimension, the output is small
             if (sk > 1 && (nk / sk < 4 || (long)tiles * sk > 1280)) continue;
             if ((long)tiles * sk * 4 < 128 && sk < 64 && nk / (2 * sk) >= 4) continue;      // far too few workgroups
-        } else if (sk > 16 || (sk > 1 && (tiles > 200 || nk < 24 || nk / sk < 6 || (long)tiles * sk > 768))) continue;
+        } else if (sk > 16 || (sk > 1 && (tiles > 200 || nk < 10 || nk / sk < 3 || (long)tiles * sk > 768))) continue;
         float t = 1e30f;
         const int id = tune_cfg(g, st, sk, &t);
         if (id < 0) continue;
@@ -886,4 +898,4 @@ extern "C" int pdmk_plan_clear(void) {
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 106; }
+extern "C" int pdmk_version(void) { return 108; }

@@ -110,6 +110,44 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                     }
                 }
             }
+        } else if (vec8 && g.epilogue == PDMK_EPI_GEGLU) {
+            // GEGLU (blocks.py:44-59) on the staged fp32 tile: columns come as (hidden, gate) blocks of 8; a thread takes
+            // one 16-column pair of a row, writes 8 outputs hidden * gelu(gate) and, for the backward, the pair itself
+            constexpr int C16 = BN / 16;
+            constexpr int ITEMS2 = (64 * C16 + NT - 1) / NT;
+            bf16* C2 = reinterpret_cast<bf16*>(g.C2);
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS2; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C16, p = item - lr2 * C16;
+                const int m = row_of(pass * 64 + lr2), n = n0 + p * 16;
+                if (!(item < 64 * C16 && m < g.M && n < g.N)) continue;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + p * 16 + q * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[q * 4 + r] = t4[r];
+                }
+                if (g.bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n + q * 4);
+                        v[q * 4] += b4.x; v[q * 4 + 1] += b4.y; v[q * 4 + 2] += b4.z; v[q * 4 + 3] += b4.w;
+                    }
+                }
+                bf16x8 hb, gb, o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { hb[r] = (bf16)v[r]; gb[r] = (bf16)v[8 + r]; }
+                if (C2) {
+                    *reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n) = hb;
+                    *reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n + 8) = gb;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16)((float)hb[r] * gelu_f((float)gb[r]));
+                *reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + (n >> 1)) = o;
+            }
         } else if (vec8) {
             // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
             bf16x8 rres[ITEMS], cprev[ITEMS];
@@ -684,8 +722,15 @@ struct Config {
 static const Config kConfigs[] = {
     {256, 4, 3, 2}, {256, 5, 3, 2}, {128, 4, 4, 2}, {128, 5, 4, 2}, {64, 4, 6, 2}, {64, 5, 5, 2},
     {128, 4, 2, 4}, {64, 4, 3, 4},  {64, 5, 2, 4},  {128, 6, 3, 2}, {64, 6, 4, 2},  {128, 5, 2, 4},
+    // small tiles for the small / short GEMMs of the 8x8 .. 32x32 levels: a workgroup's K-loop is bound by the ~70 GB/s a
+    // CU takes in from L2, so a GEMM with fewer tiles than CUs runs at (tiles / 256) of the chip's intake - more, smaller
+    // tiles (and split-K) spread it over the CUs
+    {64, 2, 4, 4},  {128, 2, 3, 4}, {64, 3, 4, 4},
 };
 constexpr int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+// candidate numbering (stable: plan files and tests name candidates by id): ring ids 0 .. kNumBase-1 = the first kNumBase
+// ring shapes, kNumBase .. kNumBase+3 = the four halo-conv shapes, then the ring shapes added later
+constexpr int kNumBase = 12;
 
 // Halo-conv shapes (candidate ids kNumConfigs + h): tile rows, channel tiles, patch capacity; eligibility of a conv.
 // Tile width for halo shape h on this conv: the image width when whole rows fit the patch buffer, else the widest
@@ -723,8 +768,8 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
     if (g.a_mode == PDMK_A_CONV && g.conv_mode == 0) {
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 159) / 160);
         const int h = (g.M >= 8192 && t256 >= 128) ? (n160 ? 0 : 1) : (n160 ? 2 : 3);
-        if (halo_ok(g, h, splitk)) return kNumConfigs + h;
-        if (halo_ok(g, h | 2, splitk)) return kNumConfigs + (h | 2);
+        if (halo_ok(g, h, splitk)) return kNumBase + h;
+        if (halo_ok(g, h | 2, splitk)) return kNumBase + (h | 2);
     }
     if (g.M >= 8192) return n160 ? S128x160 : S128x128;
     if (g.M >= 4096) return S64x160;
@@ -757,13 +802,13 @@ int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs + kNumHalo; }
 int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demangled symbol rocprofv3 reports
     using namespace pdmk_ring;
     if (id < 0 || id >= kNumConfigs + kNumHalo) return -1;
-    if (id >= kNumConfigs) {
-        const int h = id - kNumConfigs;
+    if (id >= kNumBase && id < kNumBase + kNumHalo) {
+        const int h = id - kNumBase;
         snprintf(buf, n, "pdmk_ring::conv_halo_kernel<%d, %d, %d, %d>", h < 2 ? 256 : 128, (h & 1) ? 4 : 5,
                  h < 2 ? 3 : ((h & 1) ? 5 : 4), h < 2 ? 400 : 264);
         return 0;
     }
-    const Config c = kConfigs[id];
+    const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
     snprintf(buf, n, "pdmk_ring::igemm_ring_kernel<%s, %d, %d, %d, %d>", conv ? "true" : "false", c.bm, c.nj, c.stages, c.occ);
     return 0;
 }
@@ -774,10 +819,10 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     using namespace pdmk_ring;
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
-    if (id >= kNumConfigs) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumConfigs);
-    if (id < 0) return 1;
+    if (id >= kNumBase && id < kNumBase + kNumHalo) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumBase);
+    if (id < 0 || id >= kNumConfigs + kNumHalo) return 1;
     const int sk = g.splitk > 1 ? g.splitk : 1;
-    const Config c = kConfigs[id];
+    const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
     const int bn = 32 * c.nj;
     dim3 grid(((g.M + c.bm - 1) / c.bm) * ((g.N + bn - 1) / bn), sk);
     const bool conv = g.a_mode == PDMK_A_CONV;
@@ -792,6 +837,7 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
         PDMK_RING_GO(256, 4, 3, 2) PDMK_RING_GO(256, 5, 3, 2) PDMK_RING_GO(128, 4, 4, 2) PDMK_RING_GO(128, 5, 4, 2)
         PDMK_RING_GO(64, 4, 6, 2) PDMK_RING_GO(64, 5, 5, 2) PDMK_RING_GO(128, 4, 2, 4) PDMK_RING_GO(64, 4, 3, 4)
         PDMK_RING_GO(64, 5, 2, 4) PDMK_RING_GO(128, 6, 3, 2) PDMK_RING_GO(64, 6, 4, 2) PDMK_RING_GO(128, 5, 2, 4)
+        PDMK_RING_GO(64, 2, 4, 4) PDMK_RING_GO(128, 2, 3, 4) PDMK_RING_GO(64, 3, 4, 4)
         default: return 1;
     }
 #undef PDMK_RING_GO

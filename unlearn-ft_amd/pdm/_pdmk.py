@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpdmk.so")
 
 F32, BF16 = 0, 1
+EPI_NONE, EPI_GEGLU = 0, 1
 A_ROWK, A_CONV, A_COLK = 0, 1, 2
 B_ROWK, B_COLK, B_COLK_CONV = 0, 1, 2
 
@@ -39,7 +40,8 @@ class GemmArgs(C.Structure):
                 ("rows_per_b", i32), ("a_mode", i32), ("b_mode", i32),
                 ("conv_b", i32), ("conv_hi", i32), ("conv_wi", i32), ("conv_ci", i32), ("conv_ho", i32),
                 ("conv_wo", i32), ("conv_mode", i32), ("conv_ld", i32),
-                ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32), ("ldrv", i32)]
+                ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32), ("ldrv", i32),
+                ("epilogue", i32), ("ldc2", i32), ("C2", vp)]
 
 
 _SIGS = {
@@ -56,8 +58,8 @@ _SIGS = {
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
     "pdmk_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
                        i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, vp, i64, i32, vp], i32),
-    "pdmk_geglu_fwd": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    "pdmk_geglu_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_geglu_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_geglu_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_silu_fwd": ([vp, vp, i64, i32, vp], i32),
     "pdmk_silu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
     "pdmk_copy2d": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
@@ -129,7 +131,7 @@ PROFILE = None   # bench.py sets this to a list: every gemm launch is then brack
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
-         macs=None, colsum_out=None, ldrv=0):
+         macs=None, colsum_out=None, ldrv=0, epilogue=EPI_NONE, C2=None, ldc2=0):
     # accumulate: False / True / 2 (= split-K slabs, see pdmk.h)
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
@@ -144,6 +146,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
         (g.conv_b, g.conv_hi, g.conv_wi, g.conv_ci, g.conv_ho, g.conv_wo, g.conv_mode, g.conv_ld) = conv
     g.dtype = dt(A) if dtype is None else dtype
     g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
+    g.epilogue, g.C2, g.ldc2 = int(epilogue), _p(C2), int(ldc2)
     if PROFILE is None:
         _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
         return
@@ -330,12 +333,39 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, o
          "pdmk_attn_bwd")
 
 
-def geglu_fwd(x, y, M, Fd, ldx, ldy):
-    _chk(_lib.pdmk_geglu_fwd(_p(x), _p(y), M, Fd, ldx, ldy, dt(x), _st()), "pdmk_geglu_fwd")
+def geglu_fwd(x, y, M, Fd, ldx, ldy, layout=0):
+    """layout 0: x = [h | g] halves; 1: (h, g) interleaved in blocks of 8 columns (what EPI_GEGLU consumes)."""
+    _chk(_lib.pdmk_geglu_fwd(_p(x), _p(y), M, Fd, ldx, ldy, int(layout), dt(x), _st()), "pdmk_geglu_fwd")
 
 
-def geglu_bwd(x, dy, dx, M, Fd, ldx, lddy, lddx):
-    _chk(_lib.pdmk_geglu_bwd(_p(x), _p(dy), _p(dx), M, Fd, ldx, lddy, lddx, dt(x), _st()), "pdmk_geglu_bwd")
+def geglu_bwd(x, dy, dx, M, Fd, ldx, lddy, lddx, layout=0):
+    _chk(_lib.pdmk_geglu_bwd(_p(x), _p(dy), _p(dx), M, Fd, ldx, lddy, lddx, int(layout), dt(x), _st()), "pdmk_geglu_bwd")
+
+
+def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
+    """gl[M, N/2] = GEGLU(A @ B^T + bias) in the GEMM's epilogue, (hidden, gate) columns interleaved in blocks of 8; f (or
+    None) receives the [M, N] pre-activation for the backward.  Returns False when the library has no fused kernel for
+    the shape (status -2) - the caller then runs the projection and pdmk_geglu_fwd(layout=1) as two passes."""
+    global PROFILE
+    g = GemmArgs()
+    g.A, g.B, g.C, g.bias = _p(A), _p(B), _p(gl), _p(bias)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc = lda, ldb, gl.stride(0)
+    g.a_mode, g.b_mode, g.dtype = A_ROWK, B_ROWK, dt(A)
+    g.splitk, g.alpha = 1, 1.0
+    g.epilogue, g.C2, g.ldc2 = EPI_GEGLU, _p(f), 0 if f is None else f.stride(0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.pdmk_gemm(C.byref(g), _st())
+    if rc == -2:
+        return False
+    _chk(rc, "pdmk_gemm[geglu]")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((("bf16", A_ROWK, B_ROWK, _lib.pdmk_gemm_last_candidate()), 2.0 * (macs if macs is not None else M * N * K),
+                        e0, e1, (M, N, K, 1)))
+    return True
 
 
 def silu_fwd(x, y):

@@ -46,8 +46,12 @@ class UNetEngine:
         # graph) next to the dgrad chain, which is the critical path of the backward pass
         self.temb_lay, self.temb_cols = temb_layout(cfg, blocks)
         self.kv_lay, self.kv_cols = kv_layout(blocks)
+        # skip k (push order) is concatenated behind an h of cat_ch[k] channels (None: its consumer ResBlock is dropped)
+        ups = [r for b in blocks if b.kind == "up" for r in b.resnets]
+        self.cat_ch = [None if r.dropped else padc(r.cin - r.skip) for r in reversed(ups)]
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
+        self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
 
     # ------------------------------------------------------------------ helpers
@@ -100,26 +104,48 @@ class UNetEngine:
         return max(1, min(512 // max(tiles, 1), nk // 16, 64))   # >= 16 K-steps per split (measured sweet spot)
 
     # ------------------------------------------------------------------ ops
-    def linear(self, x, key, bias=None, residual=None, out_f32=False):
+    def linear(self, x, key, bias=None, residual=None, out_f32=False, out=None, geglu=False):
+        """out: optional [M, N] view (any row stride) to write into instead of a fresh tensor (concat buffers).
+        geglu: the projection is GEGLU's (blocks.py:44-59; weight rows packed (hidden, gate)-interleaved, params.py): returns
+        hidden * gelu(gate) [M, N/2], computed in the GEMM's epilogue where the library has the fused kernel (bf16 ring
+        kernels; the pre-activation is then only written when a backward pass will need it), else as a second pass."""
         P = self.P
         e = P.by_key[key + ".weight"]
         Np, Kp = e.shape
         M = x.t.shape[0]
         assert x.t.shape[1] == Kp, f"{key}: input has {x.t.shape[1]} cols, weight expects {Kp}"
-        y = self._empty(M, Np, torch.float32 if out_f32 else None)
+        y = out if out is not None else self._empty(M, Np, torch.float32 if out_f32 else None)
+        assert tuple(y.shape) == (M, Np)
         # time-embedding MLP / batched time_emb_proj: M = batch rows -> weight-streaming kernels (skinny operand in LDS)
         skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * Kp * 4 + 512 <= 65536
         skinny_dgrad = skinny and (8 if M <= 8 else 16) * Np * 4 + 512 <= 65536
-        if skinny:
-            k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None)
+        gl = None
+        if geglu:
+            assert residual is None and out is None and not out_f32
+            gl = self._empty(M, Np // 2)
+            fused = (self.fuse_geglu and not skinny and self.dtype == torch.bfloat16 and
+                     k.splitk_plan(x.t, P.wv(key + ".weight"), M, Np, Kp, _ld(x.t), Kp) == 1)
+            if fused:
+                if not self.train:
+                    y = None                    # inference (teacher): the [M, N] pre-activation never reaches memory
+                fused = k.gemm_geglu(x.t, P.wv(key + ".weight"), gl, y, M, Np, Kp, _ld(x.t), Kp,
+                                     bias=P.p(bias) if bias else None, macs=M * e.logical[0] * e.logical[1])
+                if not fused and y is None:
+                    y = self._empty(M, Np)
+        if geglu and fused:
+            pass
+        elif skinny:
+            k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, _ld(y), bias=P.p(bias) if bias else None)
         else:
             (k.gemm if out_f32 else k.gemm_auto)(
-                x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, Np, bias=P.p(bias) if bias else None,
+                x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, _ld(y), bias=P.p(bias) if bias else None,
                 R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
                 macs=M * e.logical[0] * e.logical[1], **({"out_f32": True} if out_f32 else {}))
         lmacs = M * e.logical[0] * e.logical[1]
         if self.count_macs:
             self.macs += lmacs
+        if geglu and not fused:
+            k.geglu_fwd(y, gl, M, Np // 2, _ld(y), Np // 2, layout=1)
         out = Act(y)
         if self.train:
             def bwd():
@@ -156,9 +182,17 @@ class UNetEngine:
                     self._wgrad_fence()
                     self._give(residual, out.g)
             self.tape.append(bwd)
+        if geglu:
+            act = Act(gl)
+            if self.train:
+                def gbwd():               # runs BEFORE the projection's own backward: d(pre-activation) from d(gl)
+                    out.g = self._empty(M, Np)
+                    k.geglu_bwd(y, act.g, out.g, M, Np // 2, _ld(y), _ld(act.g), Np, layout=1)
+                self.tape.append(gbwd)
+            return act
         return out
 
-    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None):
+    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None, out=None):
         """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather; 4: stride 2
         padded on the bottom/right only (VAE encoder downsample; forward only).
         rowvec (+ rv_cols = (first column, width)): per-image row added to every pixel = this ResBlock's column slice of
@@ -169,8 +203,9 @@ class UNetEngine:
         assert x.t.shape[1] == Cip, f"{key}: input has {x.t.shape[1]} channels, weight expects {Cip}"
         Ho, Wo = ((Hi + 1) // 2, (Wi + 1) // 2) if mode in (1, 4) else ((2 * Hi, 2 * Wi) if mode == 2 else (Hi, Wi))
         M = B * Ho * Wo
-        y = self._empty(M, Cop)
-        k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, Cop, a_mode=k.A_CONV,
+        y = out if out is not None else self._empty(M, Cop)
+        assert tuple(y.shape) == (M, Cop)
+        k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
                rowvec=rowvec.t[:, rv_cols[0]:] if rowvec is not None else None, rows_per_b=Ho * Wo,
                ldrv=_ld(rowvec.t) if rowvec is not None else 0,
@@ -308,11 +343,18 @@ class UNetEngine:
             self.tape.append(bwd)
         return out
 
-    def concat(self, a, b):
+    def concat(self, a, b, cat=None):
+        """torch.cat([a, b], dim=1) of the up path.  `cat` = the [M, Ca + Cb] buffer whose right columns the
+        skip b is a view of (its producer wrote them in place); a was normally written into the left columns by ITS producer
+        (`out=`), so no copy happens at all; whatever is not in place yet is copied in."""
         M, Ca, Cb = a.t.shape[0], a.t.shape[1], b.t.shape[1]
-        cat = self._empty(M, Ca + Cb)
-        k.copy2d(a.t, cat, M, Ca, _ld(a.t), Ca + Cb)
-        k.copy2d(b.t, cat[:, Ca:], M, Cb, _ld(b.t), Ca + Cb)
+        if cat is not None and tuple(cat.shape) != (M, Ca + Cb):
+            cat = None
+        if cat is None:
+            cat = self._empty(M, Ca + Cb)
+            k.copy2d(b.t, cat[:, Ca:], M, Cb, _ld(b.t), Ca + Cb)
+        if not (a.t.data_ptr() == cat.data_ptr() and _ld(a.t) == Ca + Cb):
+            k.copy2d(a.t, cat, M, Ca, _ld(a.t), Ca + Cb)
         out = Act(cat)
         if self.train:
             def bwd():
@@ -320,6 +362,24 @@ class UNetEngine:
                 self._give(b, out.g[:, Ca:])
             self.tape.append(bwd)
         return out
+
+    def _skip_view(self, k_, M, C):
+        """(buffer, view) for the producer of skip number k_ (push order): the right C columns of its concat buffer."""
+        ch = self.cat_ch[k_] if k_ < len(self.cat_ch) else None
+        if ch is None:
+            return None, None
+        cat = self._empty(M, ch + C)
+        return cat, cat[:, ch:]
+
+    @staticmethod
+    def _left_view(skips, M, C):
+        """View for the producer of the h that the NEXT concat puts in front of the skip on top of the stack, or None."""
+        if not skips or skips[-1][1] is None:
+            return None
+        s, cat = skips[-1]
+        if cat.shape[0] != M or cat.shape[1] != C + s.t.shape[1]:
+            return None
+        return cat[:, :C]
 
     # ------------------------------------------------------------------ blocks
     def _mark(self, first_key):
@@ -334,7 +394,7 @@ class UNetEngine:
                     self.grad_ready_cb(off)
             self.tape.append(mark)
 
-    def resblock(self, x, r, st, B, H, W):
+    def resblock(self, x, r, st, B, H, W, out=None):
         G = self.cfg.norm_num_groups
         p = r.name
         self._mark(p + ".norm1.weight")
@@ -342,10 +402,10 @@ class UNetEngine:
         h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=st, rv_cols=self.temb_lay[p][:2])
         n2 = self.groupnorm(h1, p + ".norm2", B, H * W, r.groups2(G), r.cout // G, 1e-5, True)
         res = x if r.cin == r.cout else self.linear(x, p + ".conv_shortcut", bias=p + ".conv_shortcut.bias")
-        out, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res)
-        return out
+        y, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res, out=out)
+        return y
 
-    def transformer(self, x, a, ehs, B, H, W, T):
+    def transformer(self, x, a, ehs, B, H, W, T, out=None):
         G = self.cfg.norm_num_groups
         p, c, N = a.name, a.c, H * W
         t = p + ".transformer_blocks.0"
@@ -365,10 +425,9 @@ class UNetEngine:
                            ((ko, ko + d2), (ko + d2, ko + 2 * d2)))
         h = self.linear(o, t + ".attn2.to_out.0", bias=t + ".attn2.to_out.0.bias", residual=h)
         l3 = self.layernorm(h, t + ".norm3")
-        f = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias")
-        gl = self.geglu(f)
+        gl = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True)
         h = self.linear(gl, t + ".ff.net.2", bias=t + ".ff.net.2.bias", residual=h)
-        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x)
+        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out)
 
     # ------------------------------------------------------------------ whole model
     def forward(self, x, timesteps, ehs, B, H, W, train):
@@ -390,37 +449,60 @@ class UNetEngine:
         if self.kv_cols:                          # all cross-attention K/V projections in one GEMM; layers take column slices
             ehs_act = self.linear(ehs_act, "attn2_kv_all")
             ehs_act.rg = train
-        h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias")
-        skips = [h]
+        c0p = padc(c0)
+        nskip = 0
+
+        def push(act, cat):         # (skip tensor, its concat buffer or None)
+            nonlocal nskip
+            skips.append((act, cat))
+            nskip += 1
+
+        skips = []
+        cat, view = self._skip_view(nskip, B * H * W, c0p)
+        h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias", out=view)
+        push(h, cat)
         acts = {}
         for b in self.blocks:
+            cb = padc(b.c)
             if b.kind == "down":
                 for j, r in enumerate(b.resnets):
+                    att = b.attns[j] if (b.attns and not b.attns[j].dropped) else None
+                    cat, view = self._skip_view(nskip, B * H * W, cb)
+                    made = False
                     if not r.dropped:
-                        h = self.resblock(h, r, st, B, H, W)
-                    if b.attns and not b.attns[j].dropped:
-                        h = self.transformer(h, b.attns[j], ehs_act, B, H, W, T)
-                    skips.append(h)
+                        h = self.resblock(h, r, st, B, H, W, out=None if att is not None else view)
+                        made = att is None
+                    if att is not None:
+                        h = self.transformer(h, att, ehs_act, B, H, W, T, out=view)
+                        made = True
+                    # both layers dropped: the skip IS the previous tensor, which has no concat buffer for this consumer
+                    push(h, cat if made else None)
                 if b.sampler:
+                    cat, view = self._skip_view(nskip, B * ((H + 1) // 2) * ((W + 1) // 2), cb)
                     h, H, W = self.conv3(h, f"{b.name}.downsamplers.0.conv", B, H, W, 1,
-                                         f"{b.name}.downsamplers.0.conv.bias")
-                    skips.append(h)
+                                         f"{b.name}.downsamplers.0.conv.bias", out=view)
+                    push(h, cat)
                 acts[f"d{b.idx}"] = h
             elif b.kind == "mid":
                 h = self.resblock(h, b.resnets[0], st, B, H, W)
                 h = self.transformer(h, b.attns[0], ehs_act, B, H, W, T)
-                h = self.resblock(h, b.resnets[1], st, B, H, W)
+                h = self.resblock(h, b.resnets[1], st, B, H, W, out=self._left_view(skips, B * H * W, cb))
                 acts["m"] = h
             else:
+                n = len(b.resnets)
                 for j, r in enumerate(b.resnets):
-                    s = skips.pop()
+                    s, scat = skips.pop()
+                    att = b.attns[j] if (b.attns and not b.attns[j].dropped) else None
+                    # the tensor this pair leaves behind is the left half of the next concat (unless an upsampler follows)
+                    nxt = None if (j == n - 1 and b.sampler) else self._left_view(skips, B * H * W, cb)
                     if not r.dropped:      # dropped: keep the non-skip channels == h itself (blocks.py:502-515)
-                        h = self.resblock(self.concat(h, s), r, st, B, H, W)
-                    if b.attns and not b.attns[j].dropped:
-                        h = self.transformer(h, b.attns[j], ehs_act, B, H, W, T)
+                        h = self.resblock(self.concat(h, s, scat), r, st, B, H, W, out=None if att is not None else nxt)
+                    if att is not None:
+                        h = self.transformer(h, att, ehs_act, B, H, W, T, out=nxt)
                 if b.sampler:
                     h, H, W = self.conv3(h, f"{b.name}.upsamplers.0.conv", B, H, W, 2,
-                                         f"{b.name}.upsamplers.0.conv.bias")
+                                         f"{b.name}.upsamplers.0.conv.bias",
+                                         out=self._left_view(skips, B * 4 * H * W, cb))
                 acts[f"u{b.idx}"] = h
         assert not skips
         n = self.groupnorm(h, "conv_norm_out", B, H * W, cfg.norm_num_groups, c0 // cfg.norm_num_groups, 1e-5, True)

@@ -63,9 +63,15 @@ def _vec(key, srcs, rows_p=None):
 
 
 def _geglu_rows(name, ff):
-    """GEGLU proj rows [hidden | gate] (blocks.py:55): each half is padded separately so the packed row layout is
-    [h (padc(ff)) | g (padc(ff))] and the GEGLU kernel sees F = padc(ff)."""
-    return [(name, ff, 0, 0), (name, ff, padc(ff), ff)]
+    """GEGLU proj rows [hidden | gate] (blocks.py:55) packed INTERLEAVED in blocks of 8: hidden feature j sits in packed row
+    16 (j // 8) + j % 8 and its gate 8 rows further, so that one 16-column group of the projection's output holds 8 hidden
+    values and their 8 gates - what the GEMM's fused GEGLU epilogue (PDMK_EPI_GEGLU) and the layout-1 GEGLU kernels consume.
+    The packed matrix has 2 padc(ff) rows (padding rows are zero: hidden 0 * gelu(0) = 0)."""
+    out = []
+    for q in range((ff + 7) // 8):
+        n = min(8, ff - 8 * q)
+        out += [(name, n, 16 * q, 8 * q), (name, n, 16 * q + 8, ff + 8 * q)]
+    return out
 
 
 def temb_layout(cfg: UNetConfig, blocks):

@@ -188,7 +188,7 @@ class UNet2DConditionModelPruned:
         def nchw(act):
             M, C = act.t.shape
             side = int(round((M // B) ** 0.5))
-            return act.t.view(B, side, side, C).permute(0, 3, 1, 2)
+            return act.t.reshape(B, side, side, C).permute(0, 3, 1, 2)      # (a skip is a column view of its concat buffer)
         for i, h in enumerate(self.down_blocks):
             for fn in h._hooks:
                 fn(h, None, (nchw(acts[f"d{i}"]), ()))

@@ -33,8 +33,12 @@ class FusedAdamW:
         self.base_lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.m = torch.zeros_like(store.master)
         self.v = torch.zeros_like(store.master)
-        self.lr_dev = torch.zeros(1, device=dev)
-        self.bc_dev = torch.ones(2, device=dev)      # 1, not 0: a launch() before the first prepare() (graph warm-up) must not divide by 0
+        # [lr, 1 - b1^t, 1 - b2^t] live in ONE device vector refreshed per step by an asynchronous copy out of a ring of
+        # pinned host rows (a pageable H2D copy would make the host wait for the stream to drain: no run-ahead, the GPU
+        # idles between iterations); lr_dev / bc_dev are views of it
+        self._sched_dev = torch.tensor([0.0, 1.0, 1.0], device=dev)    # bc = 1, not 0: a launch() before the first prepare()
+        self.lr_dev, self.bc_dev = self._sched_dev[:1], self._sched_dev[1:]      # (graph warm-up) must not divide by 0
+        self._sched_host = torch.zeros(32, 3).pin_memory() if dev.type == "cuda" else torch.zeros(32, 3)
         self.t = 0                     # optimiser steps taken
         self.sched_k = 0               # scheduler.step() calls (accelerate steps it `sched_mult`=W times per opt step)
         self.warmup = warmup_steps     # already multiplied by W by the caller (trainer.py:436-443)
@@ -49,8 +53,9 @@ class FusedAdamW:
         """Host-side part of a step (never captured in a graph): advance t, publish lr and bias corrections."""
         self.t += 1
         lr = self.current_lr()
-        self.lr_dev.fill_(lr)
-        self.bc_dev.copy_(torch.tensor([1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t]))
+        row = self._sched_host[self.t % self._sched_host.shape[0]]      # 32 steps of run-ahead before a row is reused
+        row[0], row[1], row[2] = lr, 1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t
+        self._sched_dev.copy_(row, non_blocking=True)
         self.sched_k += self.sched_mult
         return lr
 
