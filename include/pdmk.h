@@ -230,6 +230,13 @@ int pdmk_mse_fwd(const void* a, int a_dtype, const void* b, int b_dtype, const f
 int pdmk_mse_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, void* da, int B,
                  int64_t rows_per_b, int cols, int lda, int ldb, int ldda, float gscale, int accumulate,
                  pdmk_stream stream);
+/* Both at once in ONE pass over a and b, 16-byte accesses: out[slot] += ... as pdmk_mse_fwd (out may be NULL) and, when da
+ * is not NULL, da (+)= gscale * w[b] * (a - b) as pdmk_mse_bwd.  cols % 8 == 0, row strides multiples of a 16-byte chunk,
+ * 16-byte aligned bases (-1 otherwise: use the two scalar entry points).  The block-feature head reads 2 x 6.3 M
+ * activations per image: one pass instead of two, vector loads instead of scalar ones. */
+int pdmk_mse_fwd_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, double* out, int slot,
+                     void* da, int B, int64_t rows_per_b, int cols, int lda, int ldb, int ldda, double scale,
+                     float gscale, int accumulate, pdmk_stream stream);
 /* Zero nbytes (multiple of 16, 16-byte aligned) with a kernel.  Used instead of hipMemsetAsync for split-K workspaces
  * and gradient seeds: memset nodes captured into the 2nd..nth hipGraph of a shared memory pool (the segmented backward
  * graphs of the multi-GPU path) were seen to leave the buffer unzeroed on replay (ROCm 7.2). */

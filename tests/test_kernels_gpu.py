@@ -636,3 +636,36 @@ def test_gemm_fused_geglu_epilogue(dev, force_cfg, cand):
     assert k.gemm_geglu(rnd((64, 32), dev, dt), rnd((32, 32), dev, dt), gl, None, 64, 32, 32, 32, 32) in (True, False)
     with pytest.raises(k.PdmkError):        # N not a multiple of 16
         k.gemm_geglu(rnd((64, 32), dev, dt), rnd((24, 32), dev, dt), gl, None, 64, 24, 32, 32, 32)
+
+
+@pytest.mark.parametrize("da_dt,b_dt", [("bf16", "bf16"), ("bf16", "f32"), ("f32", "f32"), ("f32", "bf16")])
+def test_mse_fused_forward_backward(dev, da_dt, b_dt):
+    """pdmk_mse_fwd_bwd: loss value + gradient seed in one vectorised pass == the two scalar kernels == torch, with per-sample
+    weights, strided rows, accumulate, forward-only and backward-only calls; odd shapes fall back to the scalar kernels."""
+    from pdm import _pdmk as k
+    torch.manual_seed(23)
+    B, rows, cols, lda, ldb = 3, 50, 40, 48, 56
+    a = rnd((B * rows, lda), dev, DT[da_dt])
+    b = rnd((B * rows, ldb), dev, DT[b_dt])
+    w = torch.rand(B, device=dev) + 0.5
+    scale, gs = 1.0 / (B * rows * cols), 0.37
+    d = a[:, :cols].float() - b[:, :cols].float()
+    wr = w.repeat_interleave(rows)[:, None]
+    ref_loss = float((d * d * wr).sum().double() * scale)
+    out = torch.zeros(4, device=dev, dtype=torch.float64)
+    da = torch.full((B * rows, cols), 2.0, device=dev, dtype=DT[da_dt])
+    k.mse_fwd_bwd(a, b, w, out, 1, da, B, rows, cols, lda, ldb, cols, scale, gs, False)
+    assert abs(float(out[1]) - ref_loss) <= 1e-5 * abs(ref_loss) and float(out[0]) == 0.0
+    close(da, gs * wr * d, TOL[da_dt], "mse seed")
+    k.mse_fwd_bwd(a, b, w, None, 0, da, B, rows, cols, lda, ldb, cols, scale, gs, True)          # backward only, accumulate
+    close(da, 2 * gs * wr * d, TOL[da_dt] * 2, "mse seed accumulated")
+    assert float(out[1]) == pytest.approx(ref_loss, rel=1e-5)
+    k.mse_fwd_bwd(a, b, None, out, 2, None, B, rows, cols, lda, ldb, cols, scale, gs, False)      # forward only, no weights
+    assert float(out[2]) == pytest.approx(float((d * d).sum().double() * scale), rel=1e-5)
+    # a shape the vector kernel does not take (cols % 8 != 0) goes through the scalar pair with the same results
+    out2 = torch.zeros(4, device=dev, dtype=torch.float64)
+    da2 = torch.zeros(B * rows, 4, device=dev, dtype=DT[da_dt])
+    k.mse_fwd_bwd(a, b, w, out2, 0, da2, B, rows, 4, lda, ldb, 4, scale, gs, False)
+    d4 = a[:, :4].float() - b[:, :4].float()
+    assert float(out2[0]) == pytest.approx(float((d4 * d4 * wr).sum().double() * scale), rel=1e-5)
+    close(da2, gs * wr * d4, TOL[da_dt], "mse seed scalar fallback")

@@ -417,6 +417,56 @@ __global__ void mse_bwd_kernel(const void* __restrict__ a, int adt, const void* 
     }
 }
 
+// Loss value AND its gradient seed in one pass, 8 elements (one or two 16-byte loads) per thread and iteration: the block
+// feature head (trainer.py:2475-2481) reads 2 x 6.3 M activations per image; the scalar kernels above stay for the
+// 4-channel prediction heads (cols not a multiple of 8).
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f);
+template <> __device__ __forceinline__ void ld8<bf16>(const bf16* p, float* f) { Vec<bf16>::load(p, f); }
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float* f) { Vec<float>::load(p, f); Vec<float>::load(p + 4, f + 4); }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* f);
+template <> __device__ __forceinline__ void st8<bf16>(bf16* p, const float* f) { Vec<bf16>::store(p, f); }
+template <> __device__ __forceinline__ void st8<float>(float* p, const float* f) { Vec<float>::store(p, f); Vec<float>::store(p + 4, f + 4); }
+
+template <typename TA, typename TB>
+__global__ __launch_bounds__(NT) void mse_vec_kernel(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                     const float* __restrict__ w, double* __restrict__ out, int slot,
+                                                     TA* __restrict__ da, long rows_per_b, int cols, int lda, int ldb,
+                                                     int ldda, double scale, float gscale, int acc) {
+    const int bi = blockIdx.y, cc = cols >> 3;
+    const long total = rows_per_b * cc;
+    const float gs = gscale * (w ? w[bi] : 1.f);
+    float s = 0.f;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / cc;
+        const int c = (int)(i - r * cc) << 3;
+        const long row = (long)bi * rows_per_b + r;
+        float x[8], y[8];
+        ld8<TA>(a + row * lda + c, x);
+        ld8<TB>(b + row * ldb + c, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[e] -= y[e]; s += x[e] * x[e]; }
+        if (da) {
+            if (acc) {
+                ld8<TA>(da + row * ldda + c, y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = gs * x[e] + y[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] *= gs;
+            }
+            st8<TA>(da + row * ldda + c, x);
+        }
+    }
+    s = wave_sum(s);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && out) {
+        const double tot = (double)red[0] + red[1] + red[2] + red[3];
+        atomicAdd(&out[slot], tot * scale * (w ? (double)w[bi] : 1.0));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ split-K finish
 // C[m][n] = (acc ? C : 0) + ws[m][n] + bias[n] + rowvec[m / rows_per_b][n] + R[m][n]   (ws: fp32 split-K partial sums)
 template <typename T>
@@ -625,6 +675,27 @@ extern "C" int pdmk_mse_fwd(const void* a, int a_dtype, const void* b, int b_dty
     dim3 grid(grid_for(rows_per_b * cols, 256), B);
     hipLaunchKernelGGL(mse_fwd_kernel, grid, dim3(NT), 0, (hipStream_t)s, a, a_dtype, b, b_dtype, w, out, slot,
                        (long)rows_per_b, cols, lda, ldb, scale);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_mse_fwd_bwd(const void* a, int a_dtype, const void* b, int b_dtype, const float* w, double* out,
+                                int slot, void* da, int B, int64_t rows_per_b, int cols, int lda, int ldb, int ldda,
+                                double scale, float gscale, int accumulate, pdmk_stream s) {
+    if (!a || !b || (!out && !da) || B <= 0 || rows_per_b <= 0 || cols <= 0) return -1;
+    if ((a_dtype | b_dtype) & ~1) return -2;
+    const int va = a_dtype == PDMK_BF16 ? 8 : 4, vb = b_dtype == PDMK_BF16 ? 8 : 4;
+    if ((cols & 7) || (lda % va) || (ldb % vb) || (da && (ldda % va)) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) ||
+        ((uintptr_t)da & 15))
+        return -1;
+    dim3 grid(grid_for(rows_per_b * (cols >> 3), 512), B);
+#define PDMK_MSEV(TA, TB)                                                                                              \
+    hipLaunchKernelGGL((mse_vec_kernel<TA, TB>), grid, dim3(NT), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, w, out, slot, \
+                       (TA*)da, (long)rows_per_b, cols, lda, ldb, ldda, scale, gscale, accumulate)
+    if (a_dtype == PDMK_BF16 && b_dtype == PDMK_BF16) PDMK_MSEV(bf16, bf16);
+    else if (a_dtype == PDMK_BF16) PDMK_MSEV(bf16, float);
+    else if (b_dtype == PDMK_BF16) PDMK_MSEV(float, bf16);
+    else PDMK_MSEV(float, float);
+#undef PDMK_MSEV
     PDMK_CHECK_LAUNCH();
     return 0;
 }

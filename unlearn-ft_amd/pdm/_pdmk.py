@@ -72,6 +72,7 @@ _SIGS = {
     "pdmk_nhwc_to_nchw": ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_mse_fwd": ([vp, i32, vp, i32, vp, vp, i32, i32, i64, i32, i32, i32, f64, vp], i32),
     "pdmk_mse_bwd": ([vp, i32, vp, i32, vp, vp, i32, i64, i32, i32, i32, i32, f32, i32, vp], i32),
+    "pdmk_mse_fwd_bwd": ([vp, i32, vp, i32, vp, vp, i32, vp, i32, i64, i32, i32, i32, i32, f64, f32, i32, vp], i32),
     "pdmk_axpby": ([vp, vp, f32, f32, i64, i32, vp], i32),
     "pdmk_adamw": ([vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp, f32, i32, vp, vp], i32),
     "pdmk_transpose_tiles": ([vp, vp, vp, i32, i32, vp], i32),
@@ -453,6 +454,22 @@ def mse_fwd(a, b, w, out, slot, B, rows_per_b, cols, lda, ldb, scale):
 def mse_bwd(a, b, w, da, B, rows_per_b, cols, lda, ldb, ldda, gscale, accumulate):
     _chk(_lib.pdmk_mse_bwd(_p(a), dt(a), _p(b), dt(b), _p(w), _p(da), B, rows_per_b, cols, lda, ldb, ldda,
                            float(gscale), int(accumulate), _st()), "pdmk_mse_bwd")
+
+
+def mse_fwd_bwd(a, b, w, out, slot, da, B, rows_per_b, cols, lda, ldb, ldda, scale, gscale, accumulate):
+    """Loss value (out[slot] +=, skipped when out is None) and gradient seed (da, skipped when None) in one vectorised pass;
+    falls back to the two scalar kernels when the shape is not 16-byte friendly."""
+    ok = cols % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0 and (da is None or da.data_ptr() % 16 == 0)
+    va, vb = (8 if a.dtype == torch.bfloat16 else 4), (8 if b.dtype == torch.bfloat16 else 4)
+    ok = ok and lda % va == 0 and ldb % vb == 0 and (da is None or ldda % va == 0)
+    if ok:
+        _chk(_lib.pdmk_mse_fwd_bwd(_p(a), dt(a), _p(b), dt(b), _p(w), _p(out), slot, _p(da), B, rows_per_b, cols, lda, ldb,
+                                   ldda, float(scale), float(gscale), int(accumulate), _st()), "pdmk_mse_fwd_bwd")
+        return
+    if out is not None:
+        mse_fwd(a, b, w, out, slot, B, rows_per_b, cols, lda, ldb, scale)
+    if da is not None:
+        mse_bwd(a, b, w, da, B, rows_per_b, cols, lda, ldb, ldda, gscale, accumulate)
 
 
 def axpby(x, y, alpha, beta):

@@ -240,13 +240,12 @@ class BilevelStepper:
             M, C = a.t.shape
             bt = b.t[t_row0:t_row0 + M]
             n = len(BLOCK_KEYS) * M * C
-            k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
-            if seed and weight > 0:
-                again = id(a) in seeded
-                if not again:
-                    a.g = torch.empty_like(a.t)
-                    seeded.add(id(a))
-                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, again)
+            again = id(a) in seeded
+            if seed and weight > 0 and not again:
+                a.g = torch.empty_like(a.t)
+                seeded.add(id(a))
+            k.mse_fwd_bwd(a.t, bt, None, self.losses, 2, a.g if (seed and weight > 0) else None, B, M // B, C,
+                          a.t.stride(0), bt.stride(0), C, 1.0 / n, 2.0 * weight / n, again)
 
     def _begin_wt_refresh(self):
         """The dgrad copies `wt` (W^T, flipped conv taps) of the weights the last optimiser step wrote are only read by the
@@ -383,13 +382,12 @@ class BilevelStepper:
             M, C = a.t.shape
             bt = b.t[M:2 * M]
             n = len(BLOCK_KEYS) * M * C
-            k.mse_fwd(a.t, bt, None, self.losses, 2, B, M // B, C, a.t.stride(0), bt.stride(0), 1.0 / n)
-            if seed:
-                again = id(a) in seeded
-                if not again:
-                    a.g = torch.empty_like(a.t)
-                    seeded.add(id(a))
-                k.mse_bwd(a.t, bt, None, a.g, B, M // B, C, a.t.stride(0), bt.stride(0), C, 2.0 * weight / n, again)
+            again = id(a) in seeded
+            if seed and not again:
+                a.g = torch.empty_like(a.t)
+                seeded.add(id(a))
+            k.mse_fwd_bwd(a.t, bt, None, self.losses, 2, a.g if seed else None, B, M // B, C, a.t.stride(0), bt.stride(0), C,
+                          1.0 / n, 2.0 * weight / n, again)
 
     def optimizer_step(self, upper=False, max_grad_norm=None):
         opt = self.upper_opt if upper else self.opt
@@ -425,12 +423,13 @@ class GraphedBilevel:
         self.t = torch.zeros(B, dtype=torch.int64, device=dev)
         self.ehs = torch.zeros(B, T, ctx, device=dev)
         self.empty = torch.zeros(B, T, ctx, device=dev)
-        # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=0 turns it off): the frozen teacher's forward of the NEXT main
-        # batch is its own graph, replayed on the teacher stream beside this iteration's student forward AND backward; its
-        # outputs are copied into static buffers once this iteration's loss heads have read the previous ones.  The
-        # teacher's ~10 ms then hide under the ~45 ms of student work instead of the ~12 ms student forward alone.
+        # Cross-step teacher prefetch (off by default; PDMK_TEACHER_PREFETCH=1 or prefetch=True): the frozen teacher's forward
+        # of the NEXT main batch is its own graph, replayed on the teacher stream beside this iteration's student forward AND
+        # backward; its outputs are copied into static buffers once this iteration's loss heads have read the previous ones.
+        # Measured on one MI355X (same-box A/B): no gain (159.3 img/s without, 157.0 with) - the GEMM kernels
+        # of the two streams each fill the CUs' LDS, so they do not co-run and the sum of kernel times is what counts.
         need_teacher = stepper.w["block"] > 0 or stepper.w["dist"] > 0
-        self.prefetch = (os.environ.get("PDMK_TEACHER_PREFETCH", "1") != "0" if prefetch is None else prefetch) and \
+        self.prefetch = (os.environ.get("PDMK_TEACHER_PREFETCH", "0") == "1" if prefetch is None else prefetch) and \
             need_teacher and stepper.teacher_stream is not None
         if self.prefetch:
             self.n_lat, self.n_noise = torch.zeros_like(self.lat), torch.zeros_like(self.noise)
