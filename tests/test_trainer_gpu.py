@@ -114,6 +114,29 @@ def test_epochs_validation_and_input_perturbation(dev, tmp_path):
         UnetFineTuner(c2)
 
 
+def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
+    """`training.hip_graphs`: Trainer.train() replays the captured step (what bench.py measures) instead of eager launches;
+    same seeded batches -> the same loss curve and the same final weights as the eager trainer (bf16 engine; split-K
+    atomics order is the only difference), same cadence and log keys."""
+    from pdm.training.trainer import BilevelUnetFineTuner
+    runs = []
+    for mode in (False, True):
+        cfg = _config(tmp_path / ("g" if mode else "e"), 6)
+        cfg["training"]["hip_graphs"] = mode
+        tr = BilevelUnetFineTuner(cfg)
+        tr.train()
+        recs = [json.loads(l) for l in open(tmp_path / ("g" if mode else "e") / "metrics.jsonl")]
+        runs.append((recs, tr.prediction_model.store.master.clone(), tr.stepper.opt.t, tr.stepper.upper_opt.t))
+    (re, we, te, ue), (rg, wg, tg, ug) = runs
+    assert (te, ue) == (tg, ug) == (6, 2) and len(re) == len(rg) == 6
+    assert [sorted(r) for r in re] == [sorted(r) for r in rg]
+    for a, b in zip(re, rg):
+        for key in a:
+            assert abs(a[key] - b[key]) <= 2e-2 * abs(a[key]) + 1e-7, (key, a[key], b[key])
+    d = (we - wg).abs()
+    assert d.max().item() <= 5e-3 and d.mean().item() <= 2e-3 * we.abs().mean().item() + 1e-6, (d.max().item(), d.mean().item())
+
+
 def test_pixel_batches_go_through_the_vae(dev, tmp_path):
     """The reference's batch schema (`pixel_values`, trainer.py:2405-2406): latents = vae.encode(...).sample() * 0.18215,
     drawn from the trainer's generator BEFORE the diffusion noise, then the same step as with pre-encoded latents."""

@@ -82,6 +82,12 @@ class Trainer:
         self.train_dataloader = train_dataloader or self.init_dataloader(upper=False)
         self.upper_dataloader = (upper_dataloader or self.init_dataloader(upper=True)) if self.bilevel else None
         self.rng = torch.Generator(device=self.device).manual_seed(int(_cfg(config, "seed", 43)) + self.rank)
+        # `training.hip_graphs: true` (CLI --hip_graphs): the step runs as hipGraph replay (GraphedBilevel: what bench.py
+        # measures - captured forward / loss heads / segmented backward, AdamW streamed behind the bucketed all-reduce)
+        # instead of eager launches.  Needs fixed batch shapes; no gradient clipping / input perturbation inside a graph.
+        self.hip_graphs = bool(_cfg(config, "training.hip_graphs", _cfg(config, "hip_graphs", False)))
+        self._graphs = None
+        self._graph_lr = {}
 
     # ---- frozen VAE (trainer.py:2128-2131, cast to the weight dtype :516-527); built on first use
     @property
@@ -270,10 +276,27 @@ class Trainer:
         t = torch.randint(0, mx, (lat.shape[0],), device=self.device, generator=self.rng).long()
         return lat, noise, t
 
+    def _graphed(self, lat, ehs):
+        """The captured step for this batch shape (built on first use; weights and optimiser state are untouched by the
+        capture's warm-up - GraphedBilevel snapshots and restores them)."""
+        from .bilevel import GraphedBilevel
+        if self.max_grad_norm is not None or self._input_noise is not None:
+            raise ValueError("training.hip_graphs does not support clip_grad_norm / input_perturbation (use eager mode)")
+        key = (tuple(lat.shape), tuple(ehs.shape))
+        if self._graphs is None or self._graphs[0] != key:
+            B, C, H, W = lat.shape
+            g = GraphedBilevel(self.stepper, B, C, H, W, ehs.shape[1], ehs.shape[2])
+            g.capture(bilevel=self.bilevel)
+            self._graphs = (key, g)
+        return self._graphs[1]
+
     def step(self, batch, backward=True):
         lat, noise, t = self._sample(batch)
-        L = self.stepper.main_step(lat, noise, t, self._prompt_embeds(batch), backward=backward,
-                                   input_noise=self._input_noise)
+        ehs = self._prompt_embeds(batch)
+        if backward and self.hip_graphs:          # graph replay: loss heads + backward + all-reduce + AdamW in one go
+            self._graph_lr["main"] = self._graphed(lat, ehs).main(lat, noise, t, ehs)
+            return self._tuple(self.stepper.losses.clone(), upper=False)
+        L = self.stepper.main_step(lat, noise, t, ehs, backward=backward, input_noise=self._input_noise)
         return self._tuple(L, upper=False)
 
     # ---- trainer.py:2490-2541
@@ -446,7 +469,8 @@ class UnetFineTuner(Trainer):
                     continue
                 stepped = True
                 loss = self.step(batch)
-                lr = self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm)
+                lr = (self._graph_lr["main"] if self.hip_graphs else
+                      self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm))
                 rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
                 keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
                 vals = [torch.stack(loss)]
@@ -457,8 +481,9 @@ class UnetFineTuner(Trainer):
                         upper_iter = iter(self.upper_dataloader)
                         ub = next(upper_iter)
                     up = self.upper_step(ub)
-                    rec["finetuning/upper_prediction_model_lr"] = self.stepper.optimizer_step(upper=True,
-                                                                                              max_grad_norm=self.max_grad_norm)
+                    rec["finetuning/upper_prediction_model_lr"] = (
+                        self._graph_lr["upper"] if self.hip_graphs else
+                        self.stepper.optimizer_step(upper=True, max_grad_norm=self.max_grad_norm))
                     keys += ("finetuning/upper_loss", "finetuning/upper_diffusion_loss",
                              "finetuning/upper_distillation_loss", "finetuning/upper_block_loss")
                     vals.append(torch.stack(up))
@@ -502,7 +527,11 @@ class BilevelUnetFineTuner(UnetFineTuner):
         lat, noise, t = self._sample(batch)
         if self._input_noise is not None:          # trainer.py:2917-2932: the upper step diffuses with the perturbed noise
             noise = self._input_noise
-        L = self.stepper.upper_step(lat, noise, t, self._prompt_embeds(batch), self._prompt_embeds(batch, empty=True))
+        ehs, empty = self._prompt_embeds(batch), self._prompt_embeds(batch, empty=True)
+        if self.hip_graphs:
+            self._graph_lr["upper"] = self._graphed(lat, ehs).upper(lat, noise, t, ehs, empty)
+            return self._tuple(self.stepper.losses.clone(), upper=True)
+        L = self.stepper.upper_step(lat, noise, t, ehs, empty)
         return self._tuple(L, upper=True)
 
 

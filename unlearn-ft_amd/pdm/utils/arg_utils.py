@@ -36,6 +36,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", action="store_true", help="seeded synthetic (latent, timestep, prompt-embed) batches")
     p.add_argument("--keep_ratio", type=float, default=0.55, help="MAC budget of the random arch vector in synthetic mode")
     p.add_argument("--tiny", action="store_true", help="tiny U-Net topology (tests / smoke)")
+    p.add_argument("--hip_graphs", action="store_true", help="replay the training step as captured hipGraphs (fixed batch shapes)")
     args = p.parse_args(argv)
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
     if env_local_rank != -1 and env_local_rank != args.local_rank:
