@@ -142,11 +142,13 @@ int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* 
                        int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps, int silu, int dtype,
                        pdmk_stream stream);
 /* dx = d(loss)/dx given dy; dgamma/dbeta (fp32 [G*gs]) are ACCUMULATED (+=).  ws: B*G*64 doubles.  part_ws: float
- * scratch for the two-stage per-channel reduction, part_ws_elems >= 2048 * 2 * G*gs is always enough (-1 if too small). */
+ * scratch for the two-stage per-channel reduction, part_ws_elems >= 2048 * 2 * G*gs is always enough (-1 if too small).
+ * add (optional, row stride ldadd): a second finished gradient of x that is folded into the same store, dx (+)= ... + add -
+ * the block's residual branch hands its gradient over this way instead of a separate read-add-write pass (blocks.py:379). */
 int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
                        const float* stats, float* dgamma, float* dbeta, double* ws, float* part_ws,
                        int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G, int gs,
-                       int silu, int accumulate_dx, int dtype, pdmk_stream stream);
+                       int silu, int accumulate_dx, const void* add, int ldadd, int dtype, pdmk_stream stream);
 /* Bytes of `ws` (forward and backward) and of `part_ws` (backward). */
 int64_t pdmk_groupnorm_workspace_bytes(int B, int G);
 int64_t pdmk_groupnorm_bwd_part_workspace_bytes(int G, int gs);

@@ -669,3 +669,33 @@ def test_mse_fused_forward_backward(dev, da_dt, b_dt):
     d4 = a[:, :4].float() - b[:, :4].float()
     assert float(out2[0]) == pytest.approx(float((d4 * d4 * wr).sum().double() * scale), rel=1e-5)
     close(da2, gs * wr * d4, TOL[da_dt], "mse seed scalar fallback")
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_groupnorm_bwd_extra_addend(dev, dn):
+    """pdmk_groupnorm_bwd(add=...): dx (+)= GN-backward + add in one store (the residual branch's gradient of the same tensor),
+    with and without accumulation into dx, strided operands."""
+    from pdm import _pdmk as k
+    torch.manual_seed(24)
+    dt = DT[dn]
+    B, HW, C, G = 2, 36, 64, 8
+    gs = C // G
+    x = rnd((B * HW, C), dev, dt)
+    gamma, beta = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    y = torch.zeros_like(x)
+    stats = torch.zeros(B, G, 2, device=dev)
+    ws = k.groupnorm_ws(dev, B, G)
+    k.groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, C, C, G, gs, 1e-5, True)
+    dy = rnd((B * HW, C), dev, dt)
+    addbuf = rnd((B * HW, C + 16), dev, dt)
+    add = addbuf[:, 8:8 + C]                                   # strided view, 16-byte aligned
+    ref = torch.zeros_like(x)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    k.groupnorm_bwd(x, dy, ref, gamma, beta, stats, dg, db, ws, B, HW, C, C, C, C, G, gs, True, False)
+    for acc in (False, True):
+        dx = rnd((B * HW, C), dev, dt)
+        base = dx.float().clone() if acc else 0.0
+        dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        k.groupnorm_bwd(x, dy, dx, gamma, beta, stats, dg2, db2, ws, B, HW, C, C, C, C, G, gs, True, acc, add=add)
+        close(dx, ref.float() + add.float() + base, TOL[dn] * 2, f"gn bwd + addend (acc={acc})")
+        close(dg2, dg, 1e-5, "dgamma unchanged")

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ stats,
                                                           const float* __restrict__ gpart, int nblk, int HW, int C,
                                                           int ldx, int lddy, int lddx, int G, int gs, int silu,
-                                                          int accumulate, int rows_per_blk) {
+                                                          int accumulate, int rows_per_blk, const T* __restrict__ add,
+                                                          int ldadd) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
     const GnMap2 mp = gn_map2(nchunks);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
         for (int sl = 0; sl < SLOTS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[UNR][V], d[UNR][V], o[UNR][V];
+                float f[UNR][V], d[UNR][V], o[UNR][V], a2[UNR][V];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int rr = r + u * mp.rif;
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                         Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
                         Vec<T>::load(dy + ((long)b * HW + rr) * lddy + c * V, d[u]);
                         if (accumulate) Vec<T>::load(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
+                        if (add) Vec<T>::load(add + ((long)b * HW + rr) * ldadd + c * V, a2[u]);
                     }
                 }
 #pragma unroll
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                             const float xh = (f[u][e] - mean[sl][e]) * rstd[sl][e];
                             float dz = d[u][e];
                             if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
-                            const float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
+                            float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
+                            if (add) v += a2[u][e];           // a second finished gradient of x (residual fan-in) folded in
                             o[u][e] = accumulate ? o[u][e] + v : v;
                         }
                         Vec<T>::store(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
@@ -450,9 +453,10 @@ int gn_fwd(const void* x, void* y, const float* gamma, const float* beta, float*
 template <typename T>
 int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta, const float* stats,
            float* dgamma, float* dbeta, double* ws, float* part, long part_elems, int B, int HW, int C, int ldx,
-           int lddy, int lddx, int G, int gs, int silu, int acc, hipStream_t st) {
+           int lddy, int lddx, int G, int gs, int silu, int acc, const void* add, int ldadd, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || lddy % V || lddx % V || G > 64 || G * gs > C || C / V > MAXS * NT || C > GN_MAXC / 8 * V) return -1;
+    if (add && ((ldadd % V) || ((uintptr_t)add & 15))) return -1;
     const GnMap2 mp = gn_map2(C / V);
     const int rpb_s = gn_rows_per_blk(B, HW, mp.rif * 4, 512, GN_MAXBLK);
     dim3 grid_s((HW + rpb_s - 1) / rpb_s, B);
@@ -468,7 +472,8 @@ int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
                            beta, stats, part, gpart, HW, C, ldx, lddy, G, gs, silu, rpb_s);                           \
         launch_reduce_partials(part, nblk, cr, dgamma, dbeta, st);                                                    \
         hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 2, S>), grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, (T*)dx,  \
-                           gamma, beta, stats, gpart, (int)grid_s.x, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb);  \
+                           gamma, beta, stats, gpart, (int)grid_s.x, HW, C, ldx, lddy, lddx, G, gs, silu, acc, rpb,   \
+                           (const T*)add, ldadd);                                                                     \
     } while (0)
     if (slots == 1) PDMK_GNB(1);
     else if (slots == 2) PDMK_GNB(2);
@@ -677,10 +682,11 @@ extern "C" int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, co
 extern "C" int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* beta,
                                   const float* stats, float* dgamma, float* dbeta, double* ws, float* part_ws,
                                   int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G,
-                                  int gs, int silu, int accumulate_dx, int dtype, pdmk_stream stream) {
+                                  int gs, int silu, int accumulate_dx, const void* add, int ldadd, int dtype,
+                                  pdmk_stream stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !ws || B <= 0 || HW <= 0) return -1;
     PDMK_DISPATCH(dtype, gn_bwd, x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, part_ws, (long)part_ws_elems, B, HW,
-                  C, ldx, lddy, lddx, G, gs, silu, accumulate_dx, (hipStream_t)stream);
+                  C, ldx, lddy, lddx, G, gs, silu, accumulate_dx, add, ldadd, (hipStream_t)stream);
 }
 extern "C" int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M,
                                   int C, int ldx, int ldy, float eps, int dtype, pdmk_stream stream) {

@@ -52,7 +52,7 @@ _SIGS = {
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
-    "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
@@ -301,11 +301,11 @@ def part_ws(device, elems):
     return buf
 
 
-def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc):
+def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc, add=None):
     pw = part_ws(x.device, _ws_bytes(_lib.pdmk_groupnorm_bwd_part_workspace_bytes(G, gs)) // 4)
     _chk(_lib.pdmk_groupnorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), _p(ws),
-                                 _p(pw), pw.numel(), B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), dt(x),
-                                 _st()), "pdmk_groupnorm_bwd")
+                                 _p(pw), pw.numel(), B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), _p(add),
+                                 0 if add is None else add.stride(0), dt(x), _st()), "pdmk_groupnorm_bwd")
 
 
 def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):

@@ -18,11 +18,29 @@ from .spec import UNetConfig, padc
 
 
 class Act:
-    """A 2-D activation [rows, cols] (row stride = t.stride(0)) and its gradient (same logical shape)."""
-    __slots__ = ("t", "g", "rg")
+    """A 2-D activation [rows, cols] (row stride = t.stride(0)) and its gradient (same logical shape).
+    pend: a second finished gradient buffer waiting to be added to `g` (the residual branch's, blocks.py:379).  Reading
+    `.g` adds it first (one strided accumulate pass); the GroupNorm backward of the same tensor - the usual next writer -
+    takes it as an extra addend of its own store instead, so the fan-in normally costs no pass at all."""
+    __slots__ = ("t", "_g", "rg", "pend")
 
     def __init__(self, t, rg=True):
-        self.t, self.g, self.rg = t, None, rg
+        self.t, self._g, self.rg, self.pend = t, None, rg, None
+
+    def flush(self):
+        if self.pend is not None:
+            p_, self.pend = self.pend, None
+            k.copy2d(p_, self._g, p_.shape[0], p_.shape[1], p_.stride(0), self._g.stride(0), accumulate=True)
+
+    @property
+    def g(self):
+        self.flush()
+        return self._g
+
+    @g.setter
+    def g(self, v):
+        assert self.pend is None
+        self._g = v
 
 
 def _ld(t):
@@ -52,27 +70,37 @@ class UNetEngine:
         self.wgrad_stream = torch.cuda.Stream(device=self.dev)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
+        self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
         return torch.empty((rows, cols), device=self.dev, dtype=dtype or self.dtype)
 
-    def _grad_into(self, act, rows, cols):
-        """Returns (tensor, accumulate) for writing d(act)."""
-        if act.g is None:
+    def _grad_into(self, act, rows, cols, absorb=False):
+        """Returns (tensor, accumulate) for writing d(act); with absorb=True (tensor, accumulate, addend): the caller's
+        kernel also adds `addend` (a pending residual gradient, or None) in the same store."""
+        add = None
+        if absorb:
+            add, act.pend = act.pend, None
+        if act._g is None:
             act.g = self._empty(rows, cols, act.t.dtype)
-            return act.g, False
-        return act.g, True
+            return (act._g, False, add) if absorb else (act._g, False)
+        act.flush()
+        return (act._g, True, add) if absorb else (act._g, True)
 
     def _give(self, act, dy):
-        """act.g += dy where dy is a finished gradient buffer (aliased when act has no gradient yet)."""
+        """act.g += dy where dy is a finished gradient buffer: aliased when act has no gradient yet, else parked as the
+        pending addend (folded in by the next GroupNorm backward of act, or on the next read of act.g)."""
         if not act.rg:
             return
-        if act.g is None:
+        if act._g is None:
             act.g = dy
+        elif self.defer_fanin and dy.dtype == act._g.dtype:
+            act.flush()
+            act.pend = dy
         else:
-            k.copy2d(dy, act.g, dy.shape[0], dy.shape[1], _ld(dy), _ld(act.g), accumulate=True)
+            k.copy2d(dy, act._g, dy.shape[0], dy.shape[1], _ld(dy), _ld(act._g), accumulate=True)
 
     def _wgrad(self, fn, *operands):
         """Launch a weight-gradient kernel.  Side stream: it starts once everything queued on the main stream so far
@@ -263,9 +291,10 @@ class UNetEngine:
         out = Act(y)
         if self.train:
             def bwd():
-                dx, acc = self._grad_into(x, B * HW, C)
-                k.groupnorm_bwd(x.t, out.g, dx, gw, gb, stats, P.g(key + ".weight"), P.g(key + ".bias"), self.ws, B,
-                                HW, C, _ld(x.t), _ld(out.g), _ld(dx), G, gs, silu, acc)
+                dy = out.g
+                dx, acc, add = self._grad_into(x, B * HW, C, absorb=True)
+                k.groupnorm_bwd(x.t, dy, dx, gw, gb, stats, P.g(key + ".weight"), P.g(key + ".bias"), self.ws, B,
+                                HW, C, _ld(x.t), _ld(dy), _ld(dx), G, gs, silu, acc, add=add)
             self.tape.append(bwd)
         return out
 

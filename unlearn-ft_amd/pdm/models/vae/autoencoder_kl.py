@@ -114,7 +114,7 @@ class _Ops(UNetEngine):
         self.dev = store.master.device
         self.ws = k.groupnorm_ws(self.dev, 64, 32)
         self.tape, self.train, self.macs, self.count_macs = [], False, 0, False
-        self.grad_ready_cb, self.wgrad_async, self._keep, self.fuse_geglu = None, False, [], True
+        self.grad_ready_cb, self.wgrad_async, self._keep, self.fuse_geglu, self.defer_fanin = None, False, [], True, False
 
 
 class _LatentDist:
