@@ -302,6 +302,21 @@ int pdmk_attn_fwd_causal(const void* q, const void* k, const void* v, void* o, f
                          float scale, int dtype, pdmk_stream stream);
 int pdmk_gelu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange: DDP's all-reduce inside accelerator.backward
+ * (pdm/training/trainer.py:117-129, 2782, 2808) as RCCL all-reduces over xGMI behind an explicit communicator handle.
+ * pdmk_comm_unique_id: rank 0 fills 128 bytes (ncclUniqueId) and hands them to the other ranks out of band (the Python
+ *   host broadcasts them over torch.distributed);  pdmk_comm_create: collective over all `world` ranks, binds the calling
+ *   thread's current HIP device;  pdmk_comm_allreduce_sum_f32: in place, asynchronous on `stream` (the caller's comm
+ *   stream: it orders it against the backward pass with events);  the mean's 1/world is folded into pdmk_adamw's grad_scale.
+ * RCCL is bound at run time (dlopen): -2 when no librccl is present, -(2000 + ncclResult) on an RCCL error. */
+typedef struct pdmk_comm* pdmk_comm_t;
+int pdmk_comm_unique_id(void* out128);
+int pdmk_comm_create(const void* id128, int rank, int world, pdmk_comm_t* out);
+int pdmk_comm_allreduce_sum_f32(pdmk_comm_t comm, float* buf, int64_t n, pdmk_stream stream);
+int pdmk_comm_world(pdmk_comm_t comm);
+int pdmk_comm_destroy(pdmk_comm_t comm);
+
 #ifdef __cplusplus
 }
 #endif

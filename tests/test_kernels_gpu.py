@@ -699,3 +699,27 @@ def test_groupnorm_bwd_extra_addend(dev, dn):
         k.groupnorm_bwd(x, dy, dx, gamma, beta, stats, dg2, db2, ws, B, HW, C, C, C, C, G, gs, True, acc, add=add)
         close(dx, ref.float() + add.float() + base, TOL[dn] * 2, f"gn bwd + addend (acc={acc})")
         close(dg2, dg, 1e-5, "dgamma unchanged")
+
+
+def test_comm_handle_single_rank_allreduce(dev):
+    """pdmk_comm_t (the C ABI's communicator handle): id -> create -> in-place fp32 all-reduce(sum) on a side stream ->
+    destroy, on a world of one rank (all this one-GPU box can host: RCCL refuses two ranks on one device; the N-rank
+    logic around it is covered by the gloo rehearsal tests)."""
+    from pdm import _pdmk as k
+    uid = k.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = k.Comm(uid, 0, 1)
+    assert k._lib.pdmk_comm_world(comm._h) == 1
+    x = torch.randn(1 << 20, device=dev)
+    ref = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        comm.all_reduce_sum_(x)
+        comm.all_reduce_sum_(x[1000:5000])
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
+    comm.close()
+    with pytest.raises(k.PdmkError):
+        k.Comm(uid, 3, 2)                       # rank outside the world

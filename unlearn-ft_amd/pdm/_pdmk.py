@@ -94,6 +94,11 @@ _SIGS = {
     "pdmk_plan_import": ([C.c_char_p], i32),
     "pdmk_plan_size": ([], i32),
     "pdmk_plan_clear": ([], i32),
+    "pdmk_comm_unique_id": ([vp], i32),
+    "pdmk_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
+    "pdmk_comm_allreduce_sum_f32": ([vp, vp, i64, vp], i32),
+    "pdmk_comm_world": ([vp], i32),
+    "pdmk_comm_destroy": ([vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
     _f = getattr(_lib, _n)          # AttributeError here = header/library mismatch: fail at import
@@ -182,6 +187,32 @@ def plan_size():
 
 def plan_clear():
     _chk(_lib.pdmk_plan_clear(), "pdmk_plan_clear")
+
+
+class Comm:
+    """pdmk_comm_t: RCCL communicator behind the C ABI (one per rank; `uid` = the 128 bytes rank 0 got from unique_id())."""
+
+    def __init__(self, uid, rank, world):
+        h = vp()
+        buf = C.create_string_buffer(bytes(uid), 128)
+        _chk(_lib.pdmk_comm_create(buf, rank, world, C.byref(h)), "pdmk_comm_create")
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _chk(_lib.pdmk_comm_unique_id(buf), "pdmk_comm_unique_id")
+        return bytes(buf.raw)
+
+    def all_reduce_sum_(self, t):
+        """In-place sum over the ranks of a contiguous fp32 tensor, asynchronous on torch's current HIP stream."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _chk(_lib.pdmk_comm_allreduce_sum_f32(self._h, _p(t), t.numel(), _st()), "pdmk_comm_allreduce_sum_f32")
+
+    def close(self):
+        if self._h is not None:
+            _lib.pdmk_comm_destroy(self._h)
+            self._h = None
 
 
 def groupnorm_ws(device, B, G, have=None):

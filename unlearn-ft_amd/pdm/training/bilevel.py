@@ -141,6 +141,14 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if (self.world > 1 and store.master.is_cuda) else None
         self.handles = []
         self.next_hi = store.total
+        # PDMK_COMM=native: the all-reduces go through the library's own communicator handle (pdmk_comm_t, RCCL bound inside
+        # libpdmk.so) instead of torch.distributed's process group; the 128-byte id travels over torch.distributed once.
+        # Default: torch.distributed (backend "nccl" = RCCL) - the path the gloo rehearsal tests cover.
+        self.comm = None
+        if self.world > 1 and store.master.is_cuda and os.environ.get("PDMK_COMM") == "native":
+            box = [k.Comm.unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm = k.Comm(box[0], dist.get_rank(), self.world)
 
     def begin(self):
         self.next_hi = self.store.total
@@ -157,13 +165,14 @@ class GradReducer:
 
     def _launch(self, lo, hi):
         g = self.store.grad[lo:hi]
+        reduce_ = self.comm.all_reduce_sum_ if self.comm is not None else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream), phase("allreduce"):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                reduce_(g)
         else:
             with phase("allreduce"):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                reduce_(g)
 
     def finish(self):
         if self.world == 1:
