@@ -258,8 +258,9 @@ def main():
             main_iter(i)
             if (i + 1) % a.upper_freq == 0:
                 upper_iter(i)
-        else:      # the NEXT main batch is announced so that its (frozen) teacher forward runs beside this step
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=(u["lat"], u["noise"], u["t"], u["ehs"]))
+        else:      # the NEXT main batches are announced: one dense (frozen) teacher forward serves a group of them
+            ups = [data[(i + j) % nb] for j in range(1, max(2, graphs.tgroup))]
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=[(q["lat"], q["noise"], q["t"], q["ehs"]) for q in ups])
             if (i + 1) % a.upper_freq == 0:
                 graphs.upper(u["lat"], u["noise"], u["t"], u["ehs"], empty)
 
@@ -296,14 +297,17 @@ def main():
         if world == 1:
             if graphs is not None:
                 d0 = data[0]
-                nx = (d0["lat"], d0["noise"], d0["t"], d0["ehs"])
-                extras["ms_main_step"] = round(timed(lambda j: graphs.main(*nx, nxt=nx), 3) * 1e3, 2)
+                tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
+                nmb = 2 * max(2, graphs.tgroup)          # whole teacher groups: the (amortised) teacher pass is in the average
+                extras["ms_main_step"] = round(timed(lambda j: graphs.main(
+                    *tup(data[j % nb]), nxt=[tup(data[(j + q) % nb]) for q in range(1, max(2, graphs.tgroup))]), nmb) * 1e3, 2)
                 extras["ms_upper_step"] = round(timed(lambda j: graphs.upper(d0["lat"], d0["noise"], d0["t"], d0["ehs"], empty), 2) * 1e3, 2)
                 st.defer_reduce = False
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
         extras["teacher_prefetch"] = bool(graphs is not None and graphs.prefetch)
+        extras["teacher_group"] = int(graphs.tgroup) if graphs is not None else 1
         if world == 1 and not a.no_vae and not a.tiny:
             # SURVEY 8f N1, NOT part of `value` (SURVEY 8d keeps the VAE off the timed path): what a pixel_values batch adds
             # in front of every step - vae.encode(pixels).latent_dist.sample() * 0.18215 (trainer.py:2405-2406)
@@ -376,8 +380,8 @@ def main():
         def two_sided(entries):
             esz = 2 if a.dtype == "bf16" else 4
             pk = (2500e12 if a.dtype == "bf16" else 157.3e12)
-            t_m = t_h = t_r = t_meas = 0.0
-            n_h = 0
+            t_m = t_h = t_r = t_meas = t_i = t_3 = 0.0
+            n_h = n_i = 0
             for kind, flops, e0, e1, (M, N, K, sk) in entries:
                 conv_a, wg = kind[1] == 1, kind[1] == 2
                 if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
@@ -385,12 +389,27 @@ def main():
                 else:
                     byts = esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
                 tm, th = 2.0 * M * N * K / pk, byts / 8e12
-                t_m, t_h, t_r = t_m + tm, t_h + th, t_r + max(tm, th)
+                # third side: what a CU can take in from L2 into LDS (~70 GB/s per CU, 18 TB/s chip-wide: MI355X_MICROARCH.md
+                # "Indexed rows: gather into LDS", tools/small_gemm_sweep.py).  An output tile BM x BN needs (BM + BN) K
+                # operand elements whatever the kernel (a halo-staged 3x3 conv reads its activation patch once per 9 taps);
+                # best case over the tile shapes a 512-thread workgroup can hold, with tiles spread over 256 CUs
+                ti = float("inf")
+                for bm in (64, 128, 256):
+                    for bn in (64, 128, 160, 256):
+                        tiles = -(-M // bm) * -(-N // bn)
+                        a_el = bm * (K / 9.0 if (conv_a or (wg and kind[2] == 2)) else K)
+                        per_cu = -(-tiles // 256) * (a_el + bn * K) * esz
+                        ti = min(ti, per_cu / 70e9)
+                t_m, t_h, t_i = t_m + tm, t_h + th, t_i + ti
+                t_r, t_3 = t_r + max(tm, th), t_3 + max(tm, th, ti)
                 n_h += th > tm
+                n_i += ti > max(tm, th)
                 t_meas += e0.elapsed_time(e1) * 1e-3
             return {"mfma_floor_ms": round(t_m * 1e3, 3), "hbm_floor_ms": round(t_h * 1e3, 3),
                     "roofline_floor_ms": round(t_r * 1e3, 3), "measured_ms": round(t_meas * 1e3, 3),
-                    "frac": round(t_r / t_meas, 4), "launches": len(entries), "hbm_bound_launches": int(n_h)}
+                    "frac": round(t_r / t_meas, 4), "launches": len(entries), "hbm_bound_launches": int(n_h),
+                    "l2_intake_floor_ms": round(t_i * 1e3, 3), "three_sided_floor_ms": round(t_3 * 1e3, 3),
+                    "three_sided_frac": round(t_3 / t_meas, 4), "intake_bound_launches": int(n_i)}
         peak = 2500.0 if a.dtype == "bf16" else 157.3
         traffic = None
         import glob
@@ -409,7 +428,8 @@ def main():
                                    f"WRITE_SIZE passes of this command, gfx950 2x FETCH_SIZE correction, keyed by kernel symbol; "
                                    f"not measured in this run: counters cannot be read live)") if traffic else None,
                 "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
-                "two_sided": {"note": "per launch max(MACs/2.5 PFLOP/s, algorithmic bytes/8 TB/s) summed, over measured time",
+                "two_sided": {"note": "per launch max(MACs/2.5 PFLOP/s, algorithmic bytes/8 TB/s) summed, over measured time; "
+                                      "three_sided adds the L2->LDS operand intake of the best 512-thread tile at 70 GB/s per CU",
                               "dominant_kernel": two_sided([p_ for p_ in prof if p_[0] == dom[0]]),
                               "all_gemms": two_sided(prof)},
                 "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),

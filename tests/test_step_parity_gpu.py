@@ -285,7 +285,9 @@ def test_teacher_prefetch_matches_in_step_teacher(dev):
     """GraphedBilevel runs the frozen teacher's forward of batch i+1 as its own graph beside the student's step on batch i
     and hands its outputs over through static buffers.  Four iterations on four different batches (with one upper step in
     between, which must not disturb the hand-over) give the same losses and parameters as computing the teacher inside
-    every step - with the next batch announced (`nxt`), and without (every call primes)."""
+    every step - with the next batch announced (`nxt`), and without (every call primes).  Teacher GROUPING (one dense
+    teacher forward over this batch and the next k-1 announced ones, each step taking its slice) gives the same too, for
+    k = 2 and 3 and when nothing is announced (the group is padded with the current batch)."""
     from pdm.training.bilevel import BilevelStepper, GraphedBilevel
     g = torch.Generator().manual_seed(5)
     batches = [tuple(x.cuda() for x in (torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g),
@@ -293,16 +295,21 @@ def test_teacher_prefetch_matches_in_step_teacher(dev):
                for _ in range(4)]
     empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous().cuda()
     results = []
-    for mode in ("in_step", "prefetch", "prime_only"):
+    for mode in ("in_step", "prefetch", "prime_only", "group2", "group3", "group2_unannounced"):
         ocfg, dense, psd, info, student, teacher = _setup(torch.float32)
         st = BilevelStepper(student, teacher, lr=1e-4, upper_lr=1e-4, bilevel=True)
-        gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3, prefetch=(mode != "in_step"))
-        assert gr.prefetch == (mode != "in_step")
+        grp = int(mode[5]) if mode.startswith("group") else 1
+        gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3, prefetch=mode in ("prefetch", "prime_only"), teacher_group=grp)
+        assert gr.prefetch == (mode in ("prefetch", "prime_only")) and gr.tgroup == grp
         gr.capture(bilevel=True)
         assert len(gr.g_main) == (2 if gr.prefetch else 1)
         losses = []
         for i, b in enumerate(batches):
-            gr.main(*b, nxt=batches[(i + 1) % 4] if mode == "prefetch" else None)
+            if mode in ("group2", "group3"):       # one dense teacher forward over this and the next grp-1 announced batches
+                nxt = [batches[(i + j) % 4] for j in range(1, grp)]
+            else:
+                nxt = batches[(i + 1) % 4] if mode == "prefetch" else None
+            gr.main(*b, nxt=nxt)
             losses.append(st.losses.clone())
             if i == 1:
                 gr.upper(*b, empty)

@@ -424,7 +424,7 @@ class GraphedBilevel:
        Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
        with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
 
-    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True, prefetch=None):
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True, prefetch=None, teacher_group=None):
         self.st = stepper
         dev = stepper.dev
         self.lat = torch.zeros(B, C, H, W, device=dev)
@@ -440,9 +440,18 @@ class GraphedBilevel:
         need_teacher = stepper.w["block"] > 0 or stepper.w["dist"] > 0
         self.prefetch = (os.environ.get("PDMK_TEACHER_PREFETCH", "0") == "1" if prefetch is None else prefetch) and \
             need_teacher and stepper.teacher_stream is not None
-        if self.prefetch:
-            self.n_lat, self.n_noise = torch.zeros_like(self.lat), torch.zeros_like(self.noise)
-            self.n_t, self.n_ehs = torch.zeros_like(self.t), torch.zeros_like(self.ehs)
+        # Teacher grouping (PDMK_TEACHER_GROUP=k or teacher_group=k, default 1 = off): the frozen teacher's forward of THIS
+        # batch and of the next k-1 announced main batches runs as ONE dense forward over k*B images (its own graph), and each
+        # of the k main steps copies its slice of the outputs into the static buffers the captured loss heads read.  The
+        # teacher does not depend on the student, so the arithmetic per image is unchanged - but its GEMMs have k times the
+        # rows, and at B = 8 the step is bound by what a small GEMM can take in per CU, not by FLOPs.
+        g_env = int(os.environ.get("PDMK_TEACHER_GROUP", "1"))
+        self.tgroup = max(1, int(teacher_group if teacher_group is not None else g_env)) if (need_teacher and not self.prefetch) else 1
+        if self.prefetch or self.tgroup > 1:
+            kb = self.tgroup * B
+            self.n_lat, self.n_noise = torch.zeros(kb, C, H, W, device=dev), torch.zeros(kb, C, H, W, device=dev)
+            self.n_t, self.n_ehs = torch.zeros(kb, dtype=torch.int64, device=dev), torch.zeros(kb, T, ctx, device=dev)
+        self._tslots = {}                    # teacher grouping: batch identity -> slot of the last grouped teacher pass
         self.g_teach = self.g_tcopy = None
         self.T_out = None                    # (pred Act, {key: Act}) static teacher outputs read by the captured loss heads
         self._primed = None                  # identity of the batch the static teacher outputs currently belong to
@@ -475,15 +484,18 @@ class GraphedBilevel:
         self.t.random_(0, 1000, generator=gen)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        if self.prefetch:
+        ext = self.prefetch or self.tgroup > 1          # the teacher runs outside the main step's graph
+        if ext:
+            G_ = self.tgroup
             for buf, src in ((self.n_lat, self.lat), (self.n_noise, self.noise), (self.n_t, self.t), (self.n_ehs, self.ehs)):
-                buf.copy_(src)
+                buf.copy_(src.repeat(G_, *([1] * (src.dim() - 1))))
         with torch.cuda.stream(side):
-            if self.prefetch:                 # static teacher-output buffers, shaped by one eager pass
+            if ext:                           # static teacher-output buffers (ONE batch), shaped by one eager pass
                 from ..models.unet.engine import Act
                 tp, ta = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
-                self.T_out = (Act(torch.empty_like(tp.t), rg=False), {k_: Act(torch.empty_like(a.t), rg=False) for k_, a in ta.items()})
-                self._copy_teacher(tp, ta)
+                one = lambda a: torch.empty((a.t.shape[0] // self.tgroup, a.t.shape[1]), device=a.t.device, dtype=a.t.dtype)
+                self.T_out = (Act(one(tp), rg=False), {k_: Act(one(a), rg=False) for k_, a in ta.items()})
+                self._copy_teacher(tp, ta, 0)
                 del tp, ta
             st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out)
             st.opt.launch(st._gscale)
@@ -492,7 +504,7 @@ class GraphedBilevel:
                 st.upper_opt.launch(st._gscale)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.prefetch:
+        if ext:
             self._capture_teacher()
         self.g_main, self.main_offs = self._capture_step(
             lambda: st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out), st.opt, cut_after_loss=self.prefetch)
@@ -513,11 +525,12 @@ class GraphedBilevel:
         store.refresh()
         torch.cuda.synchronize()
 
-    def _copy_teacher(self, pred, acts):
+    def _copy_teacher(self, pred, acts, slot=0):
+        """Slot `slot` (one batch's rows) of the teacher pass's outputs -> the static buffers the loss heads read."""
         dp, da = self.T_out
-        k.copy2d(pred.t, dp.t, pred.t.shape[0], pred.t.shape[1], pred.t.stride(0), dp.t.stride(0))
-        for key, a in acts.items():          # (the teacher is dense: no block is dropped, every key is its own activation)
-            k.copy2d(a.t, da[key].t, a.t.shape[0], a.t.shape[1], a.t.stride(0), da[key].t.stride(0))
+        for src, dst in [(pred.t, dp.t)] + [(a.t, da[key].t) for key, a in acts.items()]:   # (dense teacher: no aliased keys)
+            rows = dst.shape[0]
+            k.copy2d(src[slot * rows:(slot + 1) * rows], dst, rows, src.shape[1], src.stride(0), dst.stride(0))
 
     @staticmethod
     def _batch_id(lat, noise, t, ehs):
@@ -540,10 +553,14 @@ class GraphedBilevel:
                 self.g_teach.capture_begin(capture_error_mode="thread_local")
                 self._t_live = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
                 self.g_teach.capture_end()
-                self.g_tcopy = torch.cuda.CUDAGraph()
-                self.g_tcopy.capture_begin(capture_error_mode="thread_local")
-                self._copy_teacher(*self._t_live)
-                self.g_tcopy.capture_end()
+                self.g_tslot = []                # one copy graph per slot of a grouped pass
+                for j in range(self.tgroup):
+                    gj = torch.cuda.CUDAGraph()
+                    gj.capture_begin(capture_error_mode="thread_local")
+                    self._copy_teacher(*self._t_live, j)
+                    gj.capture_end()
+                    self.g_tslot.append(gj)
+                self.g_tcopy = self.g_tslot[0]
         finally:
             if gc_was_on:
                 gc.enable()
@@ -675,14 +692,38 @@ class GraphedBilevel:
         if teach:
             cur.wait_stream(ts)
 
+    def _grouped_teacher(self, cur, upcoming):
+        """Teacher grouping: make the static teacher outputs hold `cur`'s.  If the last grouped pass did not cover it, run
+        one over [cur] + the next tgroup-1 announced batches (short lists are padded with cur)."""
+        bid = self._batch_id(*cur)
+        if not self._tslots.get(bid):
+            group = [cur] + [b for b in (upcoming or [])][: self.tgroup - 1]
+            self._tslots = {}
+            B = cur[0].shape[0]
+            for j in range(self.tgroup):
+                b = group[j] if j < len(group) else cur
+                for buf, src in zip((self.n_lat, self.n_noise, self.n_t, self.n_ehs), b):
+                    buf[j * B:(j + 1) * B].copy_(src)
+                if j < len(group):
+                    self._tslots.setdefault(self._batch_id(*b), []).append(j)
+            self.g_teach.replay()
+        # every slot serves ONE step: a batch that comes round again gets a fresh teacher pass (nothing is cached across uses)
+        self.g_tslot[self._tslots[bid].pop(0)].replay()
+
     def main(self, lat, noise, t, ehs, nxt=None):
-        """One main step + its AdamW.  nxt = (lat, noise, t, ehs) of the NEXT main() call (teacher prefetch): its teacher
-        forward runs beside this step; without it (or on the first call) the teacher outputs of THIS batch are computed
-        up front on the teacher stream (`prime`)."""
+        """One main step + its AdamW.  nxt = the (lat, noise, t, ehs) of the NEXT main() call - or, with teacher grouping,
+        a list of the next tgroup-1 of them.  Teacher prefetch: the next batch's teacher forward runs beside this step;
+        without nxt (or on the first call) the teacher outputs of THIS batch are computed up front (`prime`).  Teacher
+        grouping: one dense teacher forward serves this and the announced batches."""
         lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches inside the step
         self._load(lat, noise, t, ehs)
         teach = False
-        if self.prefetch:
+        if self.tgroup > 1:
+            ups = None if nxt is None else ([nxt] if torch.is_tensor(nxt[0]) else list(nxt))
+            self._grouped_teacher((lat, noise, t, ehs), ups)
+        elif self.prefetch:
+            if nxt is not None and not torch.is_tensor(nxt[0]):
+                nxt = nxt[0]
             if self._primed != self._batch_id(lat, noise, t, ehs):
                 self.prime(lat, noise, t, ehs)
             if nxt is not None:
