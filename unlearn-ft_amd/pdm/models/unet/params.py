@@ -378,23 +378,36 @@ class ParamStore:
         """PyTorch-default initialisation of every logical tensor (the reference's random_init path,
         unet_2d_conditional.py:2406-2408), generated directly in packed layout on the device."""
         g = torch.Generator(device=self.master.device).manual_seed(seed)
+        dev = self.master.device
+
+        def scatter(view, e, make):
+            """One random tensor per SOURCE tensor of the entry (its logical rows), scattered to the packed rows with one
+            index_copy_ - an interleaved GEGLU projection has hundreds of 8-row pieces, not hundreds of kernels."""
+            by_name = {}
+            for name, rows, d0, s0 in e.srcs:
+                by_name.setdefault(name, []).append((rows, d0, s0))
+            for name, pieces in by_name.items():
+                total = sum(r for r, _, _ in pieces)
+                full = make(name, total)
+                dst = torch.cat([torch.arange(d0, d0 + r) for r, d0, _ in pieces]).to(dev)
+                src = torch.cat([torch.arange(s0, s0 + r) for r, _, s0 in pieces]).to(dev)
+                view.index_copy_(0, dst, full.index_select(0, src))
+
         for e in self.entries:
             view = self.master[e.off:e.off + e.numel].view(e.shape)
             view.zero_()
             if e.kind == "vec":
-                for _, rows, d0, _s0 in e.srcs:
-                    if e.key.endswith(".weight") and ("norm" in e.key):
-                        view[d0:d0 + rows] = 1.0
-                    elif e.key.endswith(".bias") and ("norm" not in e.key):
-                        fan = self._fan_in_of_bias(e.key)
-                        view[d0:d0 + rows] = (torch.rand(rows, generator=g, device=view.device) * 2 - 1) / fan ** 0.5
+                if e.key.endswith(".weight") and ("norm" in e.key):
+                    scatter(view, e, lambda name, n: torch.ones(n, device=dev))
+                elif e.key.endswith(".bias") and ("norm" not in e.key):
+                    fan = self._fan_in_of_bias(e.key)
+                    scatter(view, e, lambda name, n: (torch.rand(n, generator=g, device=dev) * 2 - 1) / fan ** 0.5)
             elif e.kind == "lin":
                 kk = e.logical[1]
-                for _, rows, d0, _s0 in e.srcs:
-                    view[d0:d0 + rows, :kk] = (torch.rand(rows, kk, generator=g, device=view.device) * 2 - 1) / kk ** 0.5
+                scatter(view[:, :kk], e, lambda name, n: (torch.rand(n, kk, generator=g, device=dev) * 2 - 1) / kk ** 0.5)
             else:
                 co, ci = e.logical
-                view[:co, :, :ci] = (torch.rand(co, 9, ci, generator=g, device=view.device) * 2 - 1) / (9 * ci) ** 0.5
+                view[:co, :, :ci] = (torch.rand(co, 9, ci, generator=g, device=dev) * 2 - 1) / (9 * ci) ** 0.5
         self.refresh()
 
     def _fan_in_of_bias(self, key):
