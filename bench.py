@@ -35,8 +35,8 @@ def parse():
     p.add_argument("--tiny", action="store_true", help="tiny topology (debug only; result is NOT the benchmark)")
     p.add_argument("--no_cpu_baseline", action="store_true")
     p.add_argument("--cpu_baseline_full", action="store_true",
-                   help="BASELINE.md 3 protocol: 3 warm-up + 5 timed main steps (median) at all host cores AND at 8 threads, "
-                        "plus the upper step (takes ~10 minutes; the default is a bounded sample of the same)")
+                   help="BASELINE.md 3 protocol: 3 warm-up + 5 timed main steps (median) at all host cores, 1 + 3 at 8 threads, "
+                        "plus the upper step (takes ~12 minutes; the default is a bounded sample of the same)")
     p.add_argument("--no_b16", action="store_true", help="skip the extra B=16/GPU measurement (shipped bilevel YAML's batch)")
     p.add_argument("--no_roofline", action="store_true")
     p.add_argument("--no_vae", action="store_true", help="skip the (untimed) VAE-encode extra")
@@ -51,7 +51,8 @@ def cpu_baseline(budget, latent, tiny, full=False):
     fwd/bwd + 3 loss heads + AdamW; warm-up steps, then the MEDIAN of the timed ones; one upper step (2 teacher fwds +
     student fwd/bwd + upper AdamW) for the bilevel blend 10*B / (10*t_main + t_upper).
     Default (bounded so that the whole bench stays within minutes): 1 warm-up + 2 timed main steps + 1 upper step at all
-    cores (~2 minutes).  --cpu_baseline_full: 3 warm-up + 5 timed at all cores AND at 8 threads (profiles/ keeps one)."""
+    cores (~2 minutes).  --cpu_baseline_full: 3 warm-up + 5 timed at all cores, then 1 warm-up + 3 timed at 8 threads
+    (~12 minutes; profiles/r02_cpu_baseline_full.json keeps one such run)."""
     import platform
     import statistics
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -113,8 +114,8 @@ def cpu_baseline(budget, latent, tiny, full=False):
                      f"budget-{budget} student + dense teacher: {first['warmup']} warm-up + {first['timed']} timed main steps "
                      f"(median {first['main_step_s_median']} s) + 1 upper step ({first['upper_step_s']} s), {all_cores} threads",
            "all_cores": first}
-    if full:
-        out["threads_8"] = run(8, 3, 5)
+    if full:      # 8 threads (the survey container's core count): 1 warm-up + 3 timed - a step takes minutes there
+        out["threads_8"] = run(8, 1, 3)
     torch.set_num_threads(all_cores)
     return out
 
