@@ -12,6 +12,11 @@ for p in (os.path.join(ROOT, "unlearn-ft_amd"), os.path.join(ROOT, "oracle"), RO
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle is the slow half of the GPU suite: torch picks one thread per hardware thread of the HOST (128 on the
+    # GPU boxes) while a one-GPU job owns 16 cores - the full-size oracle step takes 21.5 s at 128 threads and 3.9 s at 16
+    # (profiles/r02_cpu_baseline_full.json, profiles/r02_bench.json)
+    import torch
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
 
 
 @pytest.fixture(scope="session")
