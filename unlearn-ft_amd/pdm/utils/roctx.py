@@ -3,7 +3,10 @@ when a measurement asks for it, HIP-event timing of the same ranges.
 
 The reference has no tracing at all; the north_star's evidence clause needs a per-phase breakdown that does
 not depend on guessing phases from kernel symbol names.  Range names: fwd_teacher, fwd_student, loss, bwd, allreduce,
-adamw (+ diffuse, wt_refresh).  PDMK_ROCTX=0 turns the roctx calls off; they cost ~0.2 us each otherwise.
+adamw (+ diffuse, wt_refresh).  The roctx library is loaded only with PDMK_ROCTX=1 (a training process does not pull a
+profiler SDK library in by default; the HIP-event timing of the same ranges - bench.py's `extras.phases_ms_*` - works
+without it).  Run `PDMK_ROCTX=1 rocprofv3 --kernel-trace --marker-trace -- python3 bench.py ...` to see the ranges on the
+kernel timeline; keep it off for `--pmc` passes.
 """
 import ctypes
 import os
@@ -11,7 +14,7 @@ import os
 import torch
 
 _lib = None
-if os.environ.get("PDMK_ROCTX", "1") != "0":
+if os.environ.get("PDMK_ROCTX", "0") == "1":
     for _name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
         try:
             _lib = ctypes.CDLL(_name)
