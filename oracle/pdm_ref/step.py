@@ -45,45 +45,72 @@ def min_snr_weights(ac, t, gamma=5.0, v_prediction=True):
     return torch.minimum(snr, gamma * torch.ones_like(snr)) / snr
 
 
+def main_loss_heads(pred, target, full, acts_s, acts_t, ac, t, w_diff=1.0, w_block=0.1, w_dist=2.0, gamma=5.0):
+    """The three loss heads of UnetFineTuner.step (trainer.py:2451-2488) on given tensors: DDPM min-SNR(gamma) (plain MSE
+    when gamma is None), block-feature MSE averaged over the hooked blocks, output distillation; returns
+    (loss, diff, dist, block) in the reference's return order.  Pinned by tests/golden/reference_loss_heads.npz (the
+    reference's own statements executed on the same tensors)."""
+    if gamma is None:
+        l = F.mse_loss(pred.float(), target.float(), reduction="mean")
+    else:
+        w = min_snr_weights(ac, t, gamma)
+        l = F.mse_loss(pred.float(), target.float(), reduction="none")
+        l = (l.mean(dim=(1, 2, 3)) * w).mean()
+    diff = l.detach().clone()
+    loss = l * w_diff
+    block = torch.zeros(())
+    if w_block > 0:
+        for k in acts_s:
+            block = block + F.mse_loss(acts_s[k], acts_t[k].detach())
+        block = block / len(acts_s)
+        loss = loss + w_block * block
+    dist = torch.zeros(())
+    if w_dist > 0:
+        dist = F.mse_loss(pred.float(), full.float())
+        loss = loss + w_dist * dist
+    return loss, diff, dist.detach(), block.detach()
+
+
+def upper_loss_heads(pred, e_c, e_u, acts_s, acts_t, w_dist=1.0, w_block=0.0):
+    """The heads of BilevelUnetFineTuner.upper_step (trainer.py:2983-3001): negative-guidance distillation target
+    e_u - (e_c - e_u) (no .float() cast) + the block term against the teacher's LAST call; diff_loss is 0."""
+    loss = torch.zeros(())
+    block = torch.zeros(())
+    if w_block > 0:
+        for k in acts_s:
+            block = block + F.mse_loss(acts_s[k], acts_t[k].detach())
+        block = block / len(acts_s)
+        loss = loss + w_block * block
+    dist = torch.zeros(())
+    if w_dist > 0:
+        dist = F.mse_loss(pred, e_u - (e_c - e_u))
+        loss = loss + w_dist * dist
+    return loss, torch.zeros(()), dist.detach(), block.detach()
+
+
 def main_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, w_diff=1.0, w_block=0.1, w_dist=2.0, gamma=5.0):
-    """student/teacher = (sd, info).  Returns (loss, diff, dist, block) like trainer.py:2488."""
+    """student/teacher = (sd, info).  Returns (loss, diff, dist, block, pred) like trainer.py:2488."""
     noisy = add_noise(ac, latents, noise, t)
     target = get_velocity(ac, latents, noise, t)
     acts_t, acts_s = {}, {}
     with torch.no_grad():
         full = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, acts_t)
     pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
-    w = min_snr_weights(ac, t, gamma)
-    l = F.mse_loss(pred.float(), target.float(), reduction="none")
-    l = (l.mean(dim=(1, 2, 3)) * w).mean()
-    diff = l.detach().clone()
-    loss = l * w_diff
-    block = torch.zeros(())
-    if w_block > 0:
-        for k in BLOCK_KEYS:
-            block = block + F.mse_loss(acts_s[k], acts_t[k].detach())
-        block = block / len(BLOCK_KEYS)
-        loss = loss + w_block * block
-    dist = torch.zeros(())
-    if w_dist > 0:
-        dist = F.mse_loss(pred.float(), full.float())
-        loss = loss + w_dist * dist
-    return loss, diff, dist.detach(), block.detach(), pred
+    acts_s = {k: acts_s[k] for k in BLOCK_KEYS}
+    loss, diff, dist, block = main_loss_heads(pred, target, full, acts_s, acts_t, ac, t, w_diff, w_block, w_dist, gamma)
+    return loss, diff, dist, block, pred
 
 
 def upper_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, empty_ehs, w_dist=1.0, w_block=0.0):
     noisy = add_noise(ac, latents, noise, t)
     acts_t, acts_s = {}, {}
     with torch.no_grad():
-        e_c = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, acts_t)
-        e_u = unet_forward(teacher[0], cfg, teacher[1], noisy, t, empty_ehs, {})
-    # NB the reference's block hooks hold the LAST teacher call (uncond) - irrelevant while upper block weight = 0
+        e_c = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, {})
+        e_u = unet_forward(teacher[0], cfg, teacher[1], noisy, t, empty_ehs, acts_t)   # the hooks hold the LAST call (uncond)
     pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
-    loss = torch.zeros(())
-    block = torch.zeros(())
-    dist = F.mse_loss(pred, e_u - (e_c - e_u))
-    loss = loss + w_dist * dist
-    return loss, torch.zeros(()), dist.detach(), block, pred
+    acts_s = {k: acts_s[k] for k in BLOCK_KEYS}
+    loss, diff, dist, block = upper_loss_heads(pred, e_c, e_u, acts_s, acts_t, w_dist, w_block)
+    return loss, diff, dist, block, pred
 
 
 def adamw_step(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):

@@ -216,3 +216,39 @@ def test_physical_pruning_matches_reference_prune_methods():
                 assert _digest(prod[name]) == want, name
                 n += 1
         assert n > 300
+
+
+def test_loss_heads_match_reference_statements():
+    """tests/golden/reference_loss_heads.npz: the loss-head statements of UnetFineTuner.step (trainer.py:2451-2488) and
+    BilevelUnetFineTuner.upper_step (:2983-3001), executed from the reference's source on seeded tensors
+    (oracle/pin_reference_loss_heads.py).  The oracle's heads give the same four scalars and the same gradients w.r.t. the
+    student prediction and a hooked block activation, for three weight settings each (incl. snr_gamma = None, zero block /
+    distillation weights, a non-zero upper block weight)."""
+    G_ = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_loss_heads.npz"))
+    tt = lambda n: torch.from_numpy(G_[n])
+    keys = step.BLOCK_KEYS
+    ac = step.alphas_cumprod()
+    for case in range(3):
+        p = f"main{case}_"
+        gamma, wd, wb, ws = tt(p + "cfg").tolist()
+        gamma = None if gamma != gamma else gamma
+        pred = tt(p + "pred").requires_grad_(True)
+        acts_s = {k_: tt(p + "as_" + k_).requires_grad_(k_ == "m") for k_ in keys}
+        acts_t = {k_: tt(p + "at_" + k_) for k_ in keys}
+        out = step.main_loss_heads(pred, tt(p + "target"), tt(p + "full"), acts_s, acts_t, ac, tt(p + "t"), wd, wb, ws, gamma)
+        out[0].backward()
+        assert torch.allclose(torch.stack([x.detach().reshape(()) for x in out]), tt(p + "out"), rtol=1e-6, atol=1e-7), case
+        assert torch.allclose(pred.grad, tt(p + "dpred"), rtol=1e-5, atol=1e-8)
+        got = acts_s["m"].grad if acts_s["m"].grad is not None else torch.zeros_like(acts_s["m"])
+        assert torch.allclose(got, tt(p + "dact_m"), rtol=1e-5, atol=1e-9)
+        p = f"upper{case}_"
+        ws, wb = tt(p + "cfg").tolist()
+        pred = tt(p + "pred").requires_grad_(True)
+        acts_s = {k_: tt(p + "as_" + k_).requires_grad_(k_ == "m") for k_ in keys}
+        acts_t = {k_: tt(p + "at_" + k_) for k_ in keys}
+        out = step.upper_loss_heads(pred, tt(p + "e_c"), tt(p + "e_u"), acts_s, acts_t, ws, wb)
+        out[0].backward()
+        assert torch.allclose(torch.stack([x.detach().reshape(()) for x in out]), tt(p + "out"), rtol=1e-6, atol=1e-7), case
+        assert torch.allclose(pred.grad, tt(p + "dpred"), rtol=1e-5, atol=1e-8)
+        got = acts_s["m"].grad if acts_s["m"].grad is not None else torch.zeros_like(acts_s["m"])
+        assert torch.allclose(got, tt(p + "dact_m"), rtol=1e-5, atol=1e-9)

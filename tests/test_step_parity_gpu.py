@@ -134,8 +134,10 @@ def test_main_step_losses_grads_and_adamw(dev, dn):
         assert float(student.store.grad.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("dn", ["f32", "bf16"])
-def test_upper_step_matches_oracle(dev, dn):
+@pytest.mark.parametrize("dn,wb", [("f32", 0.0), ("bf16", 0.0), ("f32", 0.3)])
+def test_upper_step_matches_oracle(dev, dn, wb):
+    """wb > 0: the upper step's block term (disabled in the shipped configs) against the teacher's LAST call - the
+    unconditional half of the 2B teacher batch (trainer.py:2951-2954, 2986-2992)."""
     from pdm_ref import step as ostep, weights as oweights
     from pdm.training.bilevel import BilevelStepper
     dtype = torch.float32 if dn == "f32" else torch.bfloat16
@@ -143,14 +145,16 @@ def test_upper_step_matches_oracle(dev, dn):
     lat, noise, t, ehs, empty = _inputs()
     ac = ostep.alphas_cumprod()
     P = {k_: v.clone().requires_grad_(True) for k_, v in psd.items()}
-    loss, _, dist_, _, _ = ostep.upper_step_loss((P, info), (dense, oweights.dense_info(ocfg)), ocfg, ac, lat, noise, t,
-                                                 ehs, empty)
+    loss, _, dist_, blk, _ = ostep.upper_step_loss((P, info), (dense, oweights.dense_info(ocfg)), ocfg, ac, lat, noise, t,
+                                                   ehs, empty, w_block=wb)
     loss.backward()
-    st = BilevelStepper(student, teacher)
+    st = BilevelStepper(student, teacher, up_w_block=wb)
     L = st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda())
-    tot, _, s, _ = st.total(L, upper=True)
+    tot, _, s, b = st.total(L, upper=True)
     ltol = 2e-4 if dn == "f32" else 3e-2
     assert abs(tot - loss.item()) <= ltol * abs(loss.item()), (tot, loss.item())
+    if wb > 0:
+        assert blk.item() > 0 and abs(b - blk.item()) <= ltol * blk.item(), (b, blk.item())
     grads = student.store.state_dict(arena=student.store.grad)
     if dn == "f32":
         worst = max((_rel(grads[n], p.grad), n) for n, p in P.items())
