@@ -417,7 +417,7 @@ def force_cfg():
         os.environ.pop(var, None)
 
 
-@pytest.mark.parametrize("cand", list(range(13)) + [17, 18, 19])
+@pytest.mark.parametrize("cand", list(range(13)) + [17, 18, 19, 20, 21])
 def test_ring_gemm_every_tile_shape(dev, force_cfg, cand):
     """Every fwd/dgrad candidate of the plan cache gives the same linear + 3x3-conv results (ragged M/N/K tails, K not
     a multiple of the K-step, stride-2 / upsample / transposed gathers, split-K with fp32 atomics)."""
@@ -573,6 +573,54 @@ def test_halo_conv_candidates(dev, force_cfg, cand):
         close(y, ref, 2e-2, f"halo conv B{Bn} {Hs}x{Hs} {Ci}->{Co} sk{sk}")
 
 
+@pytest.mark.parametrize("cand", [20, 21])
+@pytest.mark.parametrize("grp", [0, 1, 3])
+def test_rowblock_linear(dev, force_cfg, cand, grp):
+    """rowblock_kernel (A rows x all of K as register fragments, weight tiles streamed through one ring over the n-tiles of a
+    column group, wave-private epilogue with the residual prefetched one n-tile ahead) vs fp32 math and - bit for bit - vs the
+    ring kernel: ragged M / N / K tails, strided A / C / R rows, bias, residual, accumulate, one and several column groups,
+    more n-tiles than ring slots, a single K-step."""
+    import os
+    from pdm import _pdmk as k
+    torch.manual_seed(31)
+    dt = torch.bfloat16
+    kmax = 320 if cand == 20 else 640
+    if grp:
+        os.environ["PDMK_RB_GRP"] = str(grp)
+    try:
+        for M, N, K, lda, ldc, ldr, mode in ((1000, 960, 320, 320, 960, 960, "bias+res"), (515, 352, 608, 616, 360, 352, "res"),
+                                             (4096, 2560, 320, 328, 2560, 0, "bias"), (300, 136, 96, 96, 136, 144, "acc"),
+                                             (129, 1288, 640, 640, 1288, 0, "plain"), (64, 8, 32, 32, 8, 8, "bias+res"),
+                                             (2048, 320, 64, 64, 328, 320, "bias+acc")):
+            if K > kmax:
+                continue
+            A = rnd((M, lda), dev, dt)
+            B = rnd((N, K), dev, dt, K ** -0.5)
+            bias = torch.randn(N, device=dev) if "bias" in mode else None
+            R = rnd((M, ldr), dev, dt) if "res" in mode else None
+            outs = []
+            for c in (cand, 4):
+                force_cfg("PDMK_RING_CFG", c)
+                C = torch.full((M, ldc), 3.0, device=dev, dtype=dt)
+                k.gemm(A, B, C, M, N, K, lda, K, ldc, bias=bias, R=R, ldr=ldr if R is not None else 0, accumulate="acc" in mode)
+                name = k.candidate_name(k.A_ROWK, k.B_ROWK, k.last_candidate())
+                assert name.startswith("pdmk_rb::rowblock_kernel" if c == cand else "pdmk_ring::igemm_ring_kernel"), name
+                outs.append(C)
+            ref = A[:, :K].float() @ B.float().t()
+            if bias is not None:
+                ref = ref + bias
+            if R is not None:
+                ref = ref + R[:, :N].float()
+            if "acc" in mode:
+                ref = ref + 3.0
+            close(outs[0][:, :N], ref, 2e-2, f"rowblock {M}x{N}x{K} {mode}")
+            assert torch.equal(outs[0], outs[1]), (M, N, K, mode, (outs[0].float() - outs[1].float()).abs().max().item())
+            if ldc > N:
+                assert float((outs[0][:, N:].float() - 3.0).abs().max()) == 0.0      # columns past N untouched
+    finally:
+        os.environ.pop("PDMK_RB_GRP", None)
+
+
 def _interleave8(h, g):
     """[.., F] hidden and gate -> [.., 2F] with (hidden, gate) interleaved in blocks of 8 columns (PDMK_EPI_GEGLU layout)."""
     F_ = h.shape[-1]
@@ -602,7 +650,7 @@ def test_geglu_interleaved_layout(dev, dn):
     assert float(dx[:, 2 * Fd:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("cand", [1, 4, 6, 8, 9, 10, 12, 17, 18, 19, -1])
+@pytest.mark.parametrize("cand", [1, 4, 6, 8, 9, 10, 12, 17, 18, 19, 20, 21, -1])
 def test_gemm_fused_geglu_epilogue(dev, force_cfg, cand):
     """PDMK_EPI_GEGLU: hidden * gelu(gate) formed in the projection's epilogue equals - bit for bit - the projection stored
     in bf16 followed by pdmk_geglu_fwd(layout 1), for every ring tile shape (ragged M, N tails of 16, K tail), with and
@@ -613,6 +661,8 @@ def test_gemm_fused_geglu_epilogue(dev, force_cfg, cand):
     torch.manual_seed(22)
     dt = torch.bfloat16
     for M, N, K in ((515, 352, 608), (200, 48, 96), (64, 32, 32), (1000, 1296, 160)):
+        if cand == 20 and K > 320:       # row-block candidate 20 keeps K <= 320 in registers (21: K <= 640)
+            continue
         A, B = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5)
         bias = torch.randn(N, device=dev)
         two = torch.zeros(M, N, device=dev, dtype=dt)

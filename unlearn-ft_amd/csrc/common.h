@@ -123,6 +123,93 @@ template <> struct Mma<float> {
     }
 };
 
+// s_waitcnt vmcnt(n) for a wave-uniform RUN-TIME n (counted LDS-DMA rings: n = DMA instructions younger than the stage
+// about to be read).  s_waitcnt only takes an immediate; a C++ switch over n compiles to a tree of 6-7 scalar compare +
+// branch pairs, measured at ~350-400 cycles per use - a third of a 64-deep K-step of a 128x160 tile.  This is a computed
+// jump into a table of 64 (s_waitcnt, s_branch) pairs: ~10 scalar instructions whatever n is.  n > 63 waits for vmcnt(63)
+// is NOT safe (it would under-wait), so larger counts clamp to 0 = wait for everything.
+__device__ __forceinline__ void pdmk_wait_vmcnt(int n) {
+    int t;
+    n = __builtin_amdgcn_readfirstlane(n);
+    asm volatile(
+        "s_cmp_gt_u32 %1, 63\n\t"
+        "s_cselect_b32 %0, 0, %1\n\t"
+        "s_lshl_b32 %0, %0, 3\n\t"
+        "s_add_u32 %0, %0, 12\n\t"
+        "s_getpc_b64 vcc\n\t"
+        "s_add_u32 vcc_lo, vcc_lo, %0\n\t"
+        "s_addc_u32 vcc_hi, vcc_hi, 0\n\t"
+        "s_setpc_b64 vcc\n\t"
+        "s_waitcnt vmcnt(0)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(1)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(2)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(3)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(4)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(5)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(6)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(7)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(8)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(9)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(10)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(11)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(12)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(13)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(14)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(15)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(16)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(17)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(18)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(19)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(20)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(21)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(22)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(23)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(24)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(25)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(26)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(27)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(28)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(29)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(30)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(31)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(32)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(33)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(34)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(35)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(36)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(37)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(38)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(39)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(40)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(41)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(42)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(43)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(44)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(45)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(46)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(47)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(48)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(49)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(50)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(51)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(52)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(53)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(54)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(55)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(56)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(57)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(58)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(59)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(60)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(61)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(62)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "s_waitcnt vmcnt(63)\n\ts_branch L_pdmk_wv_end_%=\n\t"
+        "L_pdmk_wv_end_%=:\n\t"
+        : "=&s"(t)
+        : "s"(n)
+        : "vcc", "scc", "memory");
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks b, b+8, ... share an XCD (private L2); give each XCD a
 // contiguous run of logical tiles so neighbouring tiles (shared operand panels) hit the same L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

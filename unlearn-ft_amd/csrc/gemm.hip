@@ -898,4 +898,4 @@ extern "C" int pdmk_plan_clear(void) {
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 108; }
+extern "C" int pdmk_version(void) { return 109; }

@@ -38,18 +38,7 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
     return ok ? (b * g.hi + iy) * g.wi + ix : -1;
 }
 
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {   // n is wave-uniform
-    switch (n) {
-#define PDMK_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-        PDMK_W(0) PDMK_W(1) PDMK_W(2) PDMK_W(3) PDMK_W(4) PDMK_W(5) PDMK_W(6) PDMK_W(7) PDMK_W(8) PDMK_W(9)
-        PDMK_W(10) PDMK_W(11) PDMK_W(12) PDMK_W(13) PDMK_W(14) PDMK_W(15) PDMK_W(16) PDMK_W(17) PDMK_W(18) PDMK_W(19)
-        PDMK_W(20) PDMK_W(21) PDMK_W(22) PDMK_W(23) PDMK_W(24) PDMK_W(25) PDMK_W(26) PDMK_W(27) PDMK_W(28) PDMK_W(29)
-        PDMK_W(30) PDMK_W(31) PDMK_W(32) PDMK_W(33) PDMK_W(34) PDMK_W(35) PDMK_W(36) PDMK_W(37) PDMK_W(38) PDMK_W(39)
-        PDMK_W(40) PDMK_W(41) PDMK_W(42)
-#undef PDMK_W
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // over-waits, never under-waits
-    }
-}
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) { pdmk_wait_vmcnt(n); }   // n is wave-uniform
 
 // Epilogue shared by the ring kernels (same contract as gemm.hip): accumulators -> LDS staging image (64 rows per pass) ->
 // 16-byte rows of C with bias / rowvec / residual / accumulate fused, or fp32 atomics for split-K launches.
@@ -780,6 +769,10 @@ static int pick_config(const pdmk_gemm_args& g, int splitk) {
 }  // namespace pdmk_ring
 
 constexpr int kNumHalo = 4;      // halo-conv candidates follow the ring shapes in the candidate numbering
+// row-block Linear kernels (gemm_rowblock.hip): candidate ids after every ring / halo shape
+int pdmk_gemm_rowblock_num_configs();
+int pdmk_gemm_rowblock_name(int id, char* buf, int n);
+int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id);
 static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
     using namespace pdmk_ring;
     const int tw = halo_tile_w(g, id, g.splitk);
@@ -798,10 +791,11 @@ static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_byte
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }
 
-int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs + kNumHalo; }
+int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs + kNumHalo + pdmk_gemm_rowblock_num_configs(); }
 int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demangled symbol rocprofv3 reports
     using namespace pdmk_ring;
-    if (id < 0 || id >= kNumConfigs + kNumHalo) return -1;
+    if (id >= kNumConfigs + kNumHalo) return pdmk_gemm_rowblock_name(id - (kNumConfigs + kNumHalo), buf, n);
+    if (id < 0) return -1;
     if (id >= kNumBase && id < kNumBase + kNumHalo) {
         const int h = id - kNumBase;
         snprintf(buf, n, "pdmk_ring::conv_halo_kernel<%d, %d, %d, %d>", h < 2 ? 256 : 128, (h & 1) ? 4 : 5,
@@ -820,7 +814,8 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
     if (id >= kNumBase && id < kNumBase + kNumHalo) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumBase);
-    if (id < 0 || id >= kNumConfigs + kNumHalo) return 1;
+    if (id >= kNumConfigs + kNumHalo) return pdmk_gemm_rowblock_launch(g, st, a_bytes, b_bytes, id - (kNumConfigs + kNumHalo));
+    if (id < 0) return 1;
     const int sk = g.splitk > 1 ? g.splitk : 1;
     const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
     const int bn = 32 * c.nj;
