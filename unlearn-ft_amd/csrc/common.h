@@ -20,6 +20,22 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
         if (e__ != hipSuccess) return -(1000 + (int)e__);     \
     } while (0)
 
+// Output stores of the GEMM epilogues and of the streaming kernels (vec.h) go through st_stream: plain by default,
+// non-temporal with -DPDMK_NT_STORES=1.  Measured (round 2): nt stores make an isolated Linear launch 7-10 % shorter (the
+// writer's L2 keeps its operands), but the whole training step 1 % LONGER (same-box A/B, 3 rounds: 45.2 -> 45.9 ms per main
+// step): the next launch reads these outputs, and plain stores leave them in the Infinity Cache / L2.  sc1 (write-through)
+// stores are slower already in isolation for outputs above ~20 MB.
+#ifndef PDMK_NT_STORES
+#define PDMK_NT_STORES 0
+#endif
+template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if PDMK_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void igemm_kernel(pdmk_gemm_args g, int lg
                             bf16x8 o;
 #pragma unroll
                             for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-                            *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                            st_stream(reinterpret_cast<bf16x8*>(Ct + off), o);
                         }
                     } else {
                         const int nv = min(8, g.N - n);

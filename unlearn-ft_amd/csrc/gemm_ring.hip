@@ -130,12 +130,12 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { hb[r] = (bf16)v[r]; gb[r] = (bf16)v[8 + r]; }
                 if (C2) {
-                    *reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n) = hb;
-                    *reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n + 8) = gb;
+                    st_stream(reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n), hb);
+                    st_stream(reinterpret_cast<bf16x8*>(C2 + (long)m * g.ldc2 + n + 8), gb);
                 }
 #pragma unroll
                 for (int r = 0; r < 8; ++r) o[r] = (bf16)((float)hb[r] * gelu_f((float)gb[r]));
-                *reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + (n >> 1)) = o;
+                st_stream(reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + (n >> 1)), o);
             }
         } else if (vec8) {
             // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
@@ -193,7 +193,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                     bf16x8 o;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
-                    *reinterpret_cast<bf16x8*>(Ct + off) = o;
+                    st_stream(reinterpret_cast<bf16x8*>(Ct + off), o);
                 }
             }
         } else {

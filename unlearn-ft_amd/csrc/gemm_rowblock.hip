@@ -22,6 +22,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef PDMK_RB_STORE_AUX
+#define PDMK_RB_STORE_AUX (PDMK_NT_STORES ? 2 : 0)   // cache policy of the output stores: 2 = nt (streaming; common.h st_stream), 16 = sc1 (write-through: measured slower)
+#endif
 #ifndef PDMK_RB_DEFER
 #define PDMK_RB_DEFER 0      // deferred epilogue halves: 40 more live registers (spills beside the pipelined fragments) for ~5 %
 #endif
@@ -275,11 +278,11 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
                 for (int r = 0; r < 8; ++r) o[r] = (bf16)((float)hb[r] * gelu_f((float)gb[r]));
                 if (g.C2) {                                          // wave-uniform
                     const unsigned o2 = ok ? ((unsigned)m * (unsigned)g.ldc2 + (unsigned)n) * 2u : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hb), rsrcC2, (int)o2, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gb), rsrcC2, (int)(ok ? o2 + 16u : OOB), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hb), rsrcC2, (int)o2, 0, PDMK_RB_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gb), rsrcC2, (int)(ok ? o2 + 16u : OOB), 0, PDMK_RB_STORE_AUX);
                 }
                 const unsigned oo = ok ? ((unsigned)m * (unsigned)g.ldc + (unsigned)(n >> 1)) * 2u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcC, (int)oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcC, (int)oo, 0, PDMK_RB_STORE_AUX);
             }
             issued += ITEMS2 * (g.C2 ? 3 : 1);
         } else {
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
 #pragma unroll
                 for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
                 const unsigned oo = ok ? ((unsigned)m * (unsigned)g.ldc + (unsigned)n) * 2u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcC, (int)oo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcC, (int)oo, 0, PDMK_RB_STORE_AUX);
             }
             issued += ITEMS;
         }

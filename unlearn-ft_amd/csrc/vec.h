@@ -14,7 +14,7 @@ template <> struct Vec<bf16> {
         bf16x8 v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (bf16)f[i];
-        *reinterpret_cast<bf16x8*>(p) = v;
+        st_stream(reinterpret_cast<bf16x8*>(p), v);     // outputs of the streaming kernels: consumed by later launches
     }
 };
 template <> struct Vec<float> {
@@ -24,7 +24,7 @@ template <> struct Vec<float> {
         f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
     }
     static __device__ __forceinline__ void store(float* p, const float* f) {
-        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        st_stream(reinterpret_cast<f32x4*>(p), f32x4{f[0], f[1], f[2], f[3]});
     }
 };
 

@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libpdmk.so")
+# PDMK_LIB: another build of the same library (same-box A/B of kernel variants, tools/); never a fallback - it must exist
+LIB_PATH = os.environ.get("PDMK_LIB") or os.path.join(os.path.dirname(_HERE), "libpdmk.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GEGLU = 0, 1
