@@ -150,6 +150,21 @@ int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const float* gam
                        int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G, int gs,
                        int silu, int accumulate_dx, const void* add, int ldadd, int dtype, pdmk_stream stream);
 /* Bytes of `ws` (forward and backward) and of `part_ws` (backward). */
+/* Deferred second stage of the parameter-gradient reductions.  pdmk_groupnorm_bwd / pdmk_layernorm_bwd called with
+ * dgamma = dbeta = NULL leave their per-block partials in part_ws ([nblk][2][n] floats: the *_partial_dims queries give
+ * nblk and n) and skip the reduction; the caller keeps that slab alive and later sums up to PDMK_PARTIAL_GROUP_MAX slabs
+ * into their parameter gradients (out0 += sum of part[:, 0, :], out1 += sum of part[:, 1, :]) with ONE launch - a training
+ * step has ~110 such reductions of ~7 us each for ~1 us of traffic (blocks.py GroupNorm / LayerNorm affine gradients). */
+#define PDMK_PARTIAL_GROUP_MAX 32
+typedef struct pdmk_partial_item {
+    const float* part;
+    float* out0;
+    float* out1;
+    int32_t nblk, n;
+} pdmk_partial_item;
+int pdmk_groupnorm_bwd_partial_dims(int B, int HW, int C, int G, int gs, int dtype, int32_t* nblk, int32_t* n);
+int pdmk_layernorm_bwd_partial_dims(int M, int C, int32_t* nblk, int32_t* n);
+int pdmk_reduce_partials_group(const pdmk_partial_item* items, int n_items, pdmk_stream stream);
 int64_t pdmk_groupnorm_workspace_bytes(int B, int G);
 int64_t pdmk_groupnorm_bwd_part_workspace_bytes(int G, int gs);
 

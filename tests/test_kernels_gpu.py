@@ -212,6 +212,60 @@ def test_layernorm(dev, dn, C, M):
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_deferred_partial_reductions(dev, dn):
+    """PartialQueue / pdmk_reduce_partials_group: GroupNorm and LayerNorm backward passes that leave their affine-gradient
+    partials in slabs of their own, reduced by ONE launch per <= 32 layers, give the gradients of the immediate two-stage form
+    (same slabs, same adds per address; fp32 atomics of <= 8 slices: order-dependent in the last bits only) - 40 queued layers
+    of mixed shapes (more than one group), accumulation into non-zero gradients, and the error cases of the C entry point."""
+    import ctypes as C
+    from pdm import _pdmk as k
+    torch.manual_seed(41)
+    dt = DT[dn]
+    q = k.PartialQueue()
+    cases = []
+    for i in range(40):
+        if i % 2 == 0:
+            Cc, G, gs, HW, Bn = ((320, 32, 10, 256, 2), (64, 32, 2, 64, 3), (176, 17, 10, 16, 1))[(i // 2) % 3]
+            x = rnd((Bn, HW, Cc), dev, dt) + 0.5
+            gamma, beta = torch.randn(G * gs, device=dev) * 0.3 + 1, torch.randn(G * gs, device=dev) * 0.3
+            y, stats = torch.zeros_like(x), torch.zeros(Bn, G, 2, device=dev)
+            ws = torch.zeros(Bn * G * 64, device=dev, dtype=torch.float64)
+            k.groupnorm_fwd(x, y, gamma, beta, stats, ws, Bn, HW, Cc, Cc, Cc, G, gs, 1e-5, True)
+            dy = rnd((Bn, HW, Cc), dev, dt)
+            outs = []
+            for queue in (None, q):
+                dx = torch.zeros_like(x)
+                dg, db = torch.full((G * gs,), 0.5, device=dev), torch.full((G * gs,), -0.25, device=dev)
+                k.groupnorm_bwd(x, dy, dx, gamma, beta, stats, dg, db, ws, Bn, HW, Cc, Cc, Cc, Cc, G, gs, True, False, queue=queue)
+                outs.append((dx, dg, db))
+        else:
+            M, Cc = ((300, 320), (64, 1280), (37, 64))[(i // 2) % 3]
+            x = rnd((M, Cc), dev, dt) + 0.3
+            gamma, beta = torch.randn(Cc, device=dev) * 0.3 + 1, torch.randn(Cc, device=dev) * 0.3
+            y, stats = torch.zeros_like(x), torch.zeros(M, 2, device=dev)
+            k.layernorm_fwd(x, y, gamma, beta, stats, M, Cc, Cc, Cc, 1e-5)
+            dy = rnd((M, Cc), dev, dt)
+            outs = []
+            for queue in (None, q):
+                dx = torch.zeros_like(x)
+                dg, db = torch.full((Cc,), 0.5, device=dev), torch.full((Cc,), -0.25, device=dev)
+                k.layernorm_bwd(x, dy, dx, gamma, stats, dg, db, M, Cc, Cc, Cc, Cc, False, queue=queue)
+                outs.append((dx, dg, db))
+        cases.append(outs)
+    assert 0 < len(q.items) < 40          # the queue flushed itself once when it reached 32 items
+    q.flush()
+    assert not q.items
+    torch.cuda.synchronize()
+    for (dx0, dg0, db0), (dx1, dg1, db1) in cases:
+        assert torch.equal(dx0, dx1)
+        for a, b in ((dg0, dg1), (db0, db1)):
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max() + 1e-6), "deferred reduction differs"
+    item = (k.PartialItem * 1)()
+    assert k._lib.pdmk_reduce_partials_group(C.cast(item, C.c_void_p), 1, None) == -1        # null slab
+    assert k._lib.pdmk_reduce_partials_group(C.cast(item, C.c_void_p), 33, None) == -1       # more than PDMK_PARTIAL_GROUP_MAX
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
 @pytest.mark.parametrize("Nq,Nk,H", [(100, 100, 3), (64, 77, 2), (4, 4, 1), (256, 13, 5), (1024, 77, 2), (4096, 13, 1),
                                      (4096, 4096, 2), (9216, 9216, 1), (9216, 77, 2)])   # 9216 = 96x96 latents (BASELINE configs[4])
 def test_attention(dev, dn, Nq, Nk, H):

@@ -32,9 +32,36 @@ __global__ void reduce_partials_kernel(const float* __restrict__ part, int nblk,
     if (b1 > b0) unsafeAtomicAdd(j < n ? out0 + j : out1 + (j - n), s);
 }
 inline void launch_reduce_partials(const float* part, int nblk, int n, float* out0, float* out1, hipStream_t st) {
+    if (!out0 && !out1) return;          // deferred: the caller reduces this slab later with pdmk_reduce_partials_group
     const int slices = nblk >= 256 ? 8 : (nblk >= 32 ? 4 : 1);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * n + NT - 1) / NT, slices), dim3(NT), 0, st, part, nblk, n, out0,
                        out1);
+}
+
+// The same second stage for up to PDMK_PARTIAL_GROUP_MAX slabs in ONE launch (the per-layer launches are ~7 us each for
+// ~1 us of traffic, and a training step has ~110 of them): blockIdx.y = item * 8 + slice.
+struct PartialGroup {
+    pdmk_partial_item it[PDMK_PARTIAL_GROUP_MAX];
+};
+__global__ void reduce_partials_group_kernel(PartialGroup gr) {
+    const pdmk_partial_item it = gr.it[blockIdx.y >> 3];
+    const int slice = blockIdx.y & 7, n = it.n, nblk = it.nblk;
+    const int j = blockIdx.x * NT + threadIdx.x;
+    if (j >= 2 * n) return;
+    const int per = (nblk + 7) / 8;
+    const int b0 = slice * per, b1 = min(nblk, b0 + per);
+    const float* part = it.part;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+        s0 += part[(long)b * 2 * n + j];
+        s1 += part[(long)(b + 1) * 2 * n + j];
+        s2 += part[(long)(b + 2) * 2 * n + j];
+        s3 += part[(long)(b + 3) * 2 * n + j];
+    }
+    for (; b < b1; ++b) s0 += part[(long)b * 2 * n + j];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (b1 > b0) unsafeAtomicAdd(j < n ? it.out0 + j : it.out1 + (j - n), s);
 }
 
 // ------------------------------------------------------------------------------------------------ GroupNorm
@@ -684,9 +711,43 @@ extern "C" int pdmk_groupnorm_bwd(const void* x, const void* dy, void* dx, const
                                   int64_t part_ws_elems, int B, int HW, int C, int ldx, int lddy, int lddx, int G,
                                   int gs, int silu, int accumulate_dx, const void* add, int ldadd, int dtype,
                                   pdmk_stream stream) {
-    if (!x || !dy || !dx || !gamma || !beta || !stats || !dgamma || !dbeta || !ws || B <= 0 || HW <= 0) return -1;
+    if (!x || !dy || !dx || !gamma || !beta || !stats || (!dgamma != !dbeta) || !ws || B <= 0 || HW <= 0) return -1;
     PDMK_DISPATCH(dtype, gn_bwd, x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, part_ws, (long)part_ws_elems, B, HW,
                   C, ldx, lddy, lddx, G, gs, silu, accumulate_dx, add, ldadd, (hipStream_t)stream);
+}
+/* Slab geometry of the parameter-gradient partials the two backward passes leave in part_ws ([nblk][2][n] floats). */
+extern "C" int pdmk_groupnorm_bwd_partial_dims(int B, int HW, int C, int G, int gs, int dtype, int32_t* nblk, int32_t* n) {
+    if (!nblk || !n || B <= 0 || HW <= 0 || C <= 0) return -1;
+    const int V = dtype == PDMK_BF16 ? 8 : 4;
+    if (C % V) return -1;
+    const GnMap2 mp = gn_map2(C / V);
+    const int rpb_s = gn_rows_per_blk(B, HW, mp.rif * 4, 512, GN_MAXBLK);
+    *nblk = ((HW + rpb_s - 1) / rpb_s) * B;
+    *n = G * gs;
+    return 0;
+}
+extern "C" int pdmk_layernorm_bwd_partial_dims(int M, int C, int32_t* nblk, int32_t* n) {
+    if (!nblk || !n || M <= 0 || C <= 0) return -1;
+    int rpw = (M + 1024 * 4 - 1) / (1024 * 4);
+    rpw = rpw < 4 ? 4 : (rpw > 64 ? 64 : rpw);
+    *nblk = (M + 4 * rpw - 1) / (4 * rpw);
+    *n = C;
+    return 0;
+}
+extern "C" int pdmk_reduce_partials_group(const pdmk_partial_item* items, int n_items, pdmk_stream stream) {
+    if (!items || n_items <= 0 || n_items > PDMK_PARTIAL_GROUP_MAX) return -1;
+    PartialGroup gr;
+    int nmax = 0;
+    for (int i = 0; i < n_items; ++i) {
+        if (!items[i].part || !items[i].out0 || !items[i].out1 || items[i].nblk <= 0 || items[i].n <= 0) return -1;
+        gr.it[i] = items[i];
+        nmax = items[i].n > nmax ? items[i].n : nmax;
+    }
+    for (int i = n_items; i < PDMK_PARTIAL_GROUP_MAX; ++i) gr.it[i] = items[0];
+    hipLaunchKernelGGL(reduce_partials_group_kernel, dim3((2 * nmax + NT - 1) / NT, n_items * 8), dim3(NT), 0,
+                       (hipStream_t)stream, gr);
+    PDMK_CHECK_LAUNCH();
+    return 0;
 }
 extern "C" int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M,
                                   int C, int ldx, int ldy, float eps, int dtype, pdmk_stream stream) {
@@ -696,7 +757,7 @@ extern "C" int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, co
 extern "C" int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
                                   float* dgamma, float* dbeta, float* part_ws, int64_t part_ws_elems, int M, int C,
                                   int ldx, int lddy, int lddx, int accumulate_dx, int dtype, pdmk_stream stream) {
-    if (!x || !dy || !dx || !gamma || !stats || !dgamma || !dbeta || M <= 0) return -1;
+    if (!x || !dy || !dx || !gamma || !stats || (!dgamma != !dbeta) || M <= 0) return -1;
     PDMK_DISPATCH(dtype, ln_bwd, x, dy, dx, gamma, stats, dgamma, dbeta, part_ws, (long)part_ws_elems, M, C, ldx, lddy,
                   lddx, accumulate_dx, (hipStream_t)stream);
 }

@@ -54,6 +54,9 @@ _SIGS = {
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], i32),
+    "pdmk_groupnorm_bwd_partial_dims": ([i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
+    "pdmk_layernorm_bwd_partial_dims": ([i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
+    "pdmk_reduce_partials_group": ([vp, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
@@ -333,8 +336,51 @@ def part_ws(device, elems):
     return buf
 
 
-def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc, add=None):
-    pw = part_ws(x.device, _ws_bytes(_lib.pdmk_groupnorm_bwd_part_workspace_bytes(G, gs)) // 4)
+class PartialItem(C.Structure):
+    _fields_ = [("part", vp), ("out0", vp), ("out1", vp), ("nblk", i32), ("n", i32)]
+
+
+PARTIAL_GROUP_MAX = 32
+
+
+class PartialQueue:
+    """Deferred second stage of the GroupNorm / LayerNorm parameter-gradient reductions (pdmk.h): each backward call leaves
+    its per-block partials in a slab of its own; flush() sums up to 32 slabs per launch into dgamma / dbeta."""
+
+    def __init__(self):
+        self.items = []          # (slab tensor, dgamma, dbeta, nblk, n): the slab stays referenced until the flush
+
+    def slab(self, device, nblk, n, dgamma, dbeta):
+        if len(self.items) >= PARTIAL_GROUP_MAX:       # before the new slab joins: its kernel has not been launched yet
+            self.flush()
+        t = torch.empty(nblk * 2 * n, device=device, dtype=torch.float32)
+        self.items.append((t, dgamma, dbeta, nblk, n))
+        return t
+
+    def flush(self):
+        while self.items:
+            chunk, self.items = self.items[:PARTIAL_GROUP_MAX], self.items[PARTIAL_GROUP_MAX:]
+            arr = (PartialItem * len(chunk))()
+            for a, (t, g0, g1, nblk, n) in zip(arr, chunk):
+                a.part, a.out0, a.out1, a.nblk, a.n = _p(t), _p(g0), _p(g1), nblk, n
+            _chk(_lib.pdmk_reduce_partials_group(C.cast(arr, vp), len(chunk), _st()), "pdmk_reduce_partials_group")
+
+
+def _dims(fn, *args):
+    a, b = i32(0), i32(0)
+    _chk(fn(*args, C.byref(a), C.byref(b)), fn.__name__)
+    return a.value, b.value
+
+
+def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, ldx, lddy, lddx, G, gs, silu, acc, add=None,
+                  queue=None):
+    """queue: a PartialQueue - the dgamma / dbeta reduction is deferred to its next flush (one launch for many layers)."""
+    if queue is not None:
+        nblk, n = _dims(_lib.pdmk_groupnorm_bwd_partial_dims, B, HW, Cc, G, gs, dt(x))
+        pw = queue.slab(x.device, nblk, n, dgamma, dbeta)
+        dgamma = dbeta = None
+    else:
+        pw = part_ws(x.device, _ws_bytes(_lib.pdmk_groupnorm_bwd_part_workspace_bytes(G, gs)) // 4)
     _chk(_lib.pdmk_groupnorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(beta), _p(stats), _p(dgamma), _p(dbeta), _p(ws),
                                  _p(pw), pw.numel(), B, HW, Cc, ldx, lddy, lddx, G, gs, int(silu), int(acc), _p(add),
                                  0 if add is None else add.stride(0), dt(x), _st()), "pdmk_groupnorm_bwd")
@@ -345,8 +391,13 @@ def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
          "pdmk_layernorm_fwd")
 
 
-def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc):
-    pw = part_ws(x.device, _ws_bytes(_lib.pdmk_layernorm_bwd_part_workspace_bytes(M, Cc)) // 4)
+def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc, queue=None):
+    if queue is not None:
+        nblk, n = _dims(_lib.pdmk_layernorm_bwd_partial_dims, M, Cc)
+        pw = queue.slab(x.device, nblk, n, dgamma, dbeta)
+        dgamma = dbeta = None
+    else:
+        pw = part_ws(x.device, _ws_bytes(_lib.pdmk_layernorm_bwd_part_workspace_bytes(M, Cc)) // 4)
     _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), _p(pw),
                                  pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
 

@@ -72,6 +72,9 @@ class UNetEngine:
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
+        # GroupNorm / LayerNorm affine gradients: the second-stage reductions of a whole block run as one launch at the
+        # block boundary (PDMK_DEFER_PARTIALS=0: one launch per layer, as before)
+        self.partials = k.PartialQueue() if os.environ.get("PDMK_DEFER_PARTIALS", "1") != "0" else None
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -124,6 +127,13 @@ class UNetEngine:
         in place by later main-stream kernels: make the main stream wait for the side stream first."""
         if self.wgrad_async:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def flush_pending(self):
+        """Deferred norm-affine gradient reductions (PartialQueue): after this every gradient the tape has produced so far is
+        final in the arena.  Called by whoever consumes gradients mid-backward (bucketed all-reduce, streamed AdamW, graph
+        cut) and at the end of backward()."""
+        if self.partials is not None:
+            self.partials.flush()
 
     @staticmethod
     def _splitk(m_out, n_out, red, step):
@@ -294,7 +304,7 @@ class UNetEngine:
                 dy = out.g
                 dx, acc, add = self._grad_into(x, B * HW, C, absorb=True)
                 k.groupnorm_bwd(x.t, dy, dx, gw, gb, stats, P.g(key + ".weight"), P.g(key + ".bias"), self.ws, B,
-                                HW, C, _ld(x.t), _ld(dy), _ld(dx), G, gs, silu, acc, add=add)
+                                HW, C, _ld(x.t), _ld(dy), _ld(dx), G, gs, silu, acc, add=add, queue=self.partials)
             self.tape.append(bwd)
         return out
 
@@ -310,7 +320,7 @@ class UNetEngine:
             def bwd():
                 dx, acc = self._grad_into(x, M, C)
                 k.layernorm_bwd(x.t, out.g, dx, gw, stats, P.g(key + ".weight"), P.g(key + ".bias"), M, C, _ld(x.t),
-                                _ld(out.g), _ld(dx), acc)
+                                _ld(out.g), _ld(dx), acc, queue=self.partials)
             self.tape.append(bwd)
         return out
 
@@ -419,7 +429,7 @@ class UNetEngine:
 
             def mark():
                 self._join_wgrad()         # block boundary: side-stream wgrads of this block are done, operands freed
-                if self.grad_ready_cb:
+                if self.grad_ready_cb:     # a consumer that acts on [off, total) calls flush_pending() first
                     self.grad_ready_cb(off)
             self.tape.append(mark)
 
@@ -544,3 +554,4 @@ class UNetEngine:
         for fn in reversed(tape):
             fn()
         self._join_wgrad()
+        self.flush_pending()

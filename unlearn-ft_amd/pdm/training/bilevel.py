@@ -141,6 +141,7 @@ class GradReducer:
         self.stream = torch.cuda.Stream() if (self.world > 1 and store.master.is_cuda) else None
         self.handles = []
         self.next_hi = store.total
+        self.flush_cb = None               # set by the stepper: the engine's flush_pending()
         # PDMK_COMM=native: the all-reduces go through the library's own communicator handle (pdmk_comm_t, RCCL bound inside
         # libpdmk.so) instead of torch.distributed's process group; the 128-byte id travels over torch.distributed once.
         # Default: torch.distributed (backend "nccl" = RCCL) - the path the gloo rehearsal tests cover.
@@ -160,6 +161,8 @@ class GradReducer:
             return
         lo = max(lo, 0)
         while self.next_hi - lo >= self.bucket:
+            if self.flush_cb is not None:
+                self.flush_cb()            # deferred norm-affine gradient reductions of the blocks behind `lo`
             self._launch(self.next_hi - self.bucket, self.next_hi)
             self.next_hi -= self.bucket
 
@@ -207,6 +210,7 @@ class BilevelStepper:
         self.upper_opt = FusedAdamW(student.store, upper_lr, betas, eps, weight_decay, upper_warmup_steps * world,
                                     world) if bilevel else None
         self.reducer = GradReducer(student.store, bucket_mb)
+        self.reducer.flush_cb = student.engine.flush_pending
         self.defer_reduce = False
         self.segment_cb = None
         self.after_loss_cb = None      # GraphedBilevel: cut the captured graph between the loss heads and the backward
@@ -600,6 +604,7 @@ class GraphedBilevel:
         def seg_cb(off):
             if state["n"] < len(cuts) and off <= cuts[state["n"]]:
                 state["n"] += 1
+                st.student.engine.flush_pending()      # gradients in [off, total) are final only after this
                 if multi:
                     graphs[-1].capture_end()
                     offs.append(off)
