@@ -119,6 +119,20 @@ int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float*
                        int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int nslab /* slabs in ws */,
                        int accumulate, int dtype, pdmk_stream stream);
 /* Bytes of the fp32 slab workspace of a split-K forward / dgrad GEMM ([splitk][M][N]); -1 on bad arguments. */
+/* Weight gradients (a_mode = PDMK_A_COLK) also take accumulate = 2: split z then stores its partial dW into slab z of a
+ * [splitk][M][N] fp32 workspace (ldc = N) instead of adding into the gradient with float atomics (~1.3 TB/s chip-wide: for
+ * the 320 x 320 projections of the 64 x 64 level that is half of the kernel).  The caller keeps the workspace and later adds
+ * the slabs of up to PDMK_SLAB_GROUP_MAX weights into their gradients with ONE launch: dst[e] += sum_s ws[s * n + e], slabs
+ * added in a fixed order (bit-reproducible).  n = M * N elements (a multiple of 4), ws and dst 16-byte aligned, dst
+ * contiguous.  Replaces the accumulation side of every nn.Linear weight gradient reached from blocks.py:244-285, 44-76. */
+#define PDMK_SLAB_GROUP_MAX 32
+typedef struct pdmk_slab_item {
+    const float* ws;
+    float* dst;
+    int64_t n;
+    int32_t nslab, pad_;
+} pdmk_slab_item;
+int pdmk_splitk_finish_group(const pdmk_slab_item* items, int n_items, pdmk_stream stream);
 int64_t pdmk_gemm_splitk_workspace_bytes(int64_t M, int N, int splitk);
 
 /* Plan cache (the library's only state).  pdmk_plan_export writes every cached (shape -> candidate / split-K) decision to

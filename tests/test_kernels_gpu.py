@@ -211,6 +211,43 @@ def test_layernorm(dev, dn, C, M):
     close(dbt, gb, TOL[dn] * 2, "ln dbeta")
 
 
+@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 5])
+def test_wgrad_slabs_and_grouped_finish(dev, force_cfg, cand):
+    """Weight gradients whose splits store partial slabs (accumulate = 2 on the reduction-major path) and
+    pdmk_splitk_finish_group adding the slabs of many weights in one launch: equal to fp32 math, and bit-reproducible
+    (two runs give identical gradients - the atomic form does not promise that); 35 queued weights flush in two launches;
+    the planner's slab-mode split factor is used; error cases of the C entry point."""
+    import ctypes as C
+    from pdm import _pdmk as k
+    if cand >= 0:
+        force_cfg("PDMK_WGRAD_CFG", cand)
+    torch.manual_seed(33)
+    dt = torch.bfloat16
+    runs = []
+    for rep in range(2):
+        q = k.SlabQueue()
+        outs = []
+        torch.manual_seed(34)
+        for i in range(35):
+            P, No, Ki = ((4096, 320, 352), (2048, 96, 160), (8192, 64, 64), (1000, 160, 288))[i % 4]
+            dY, X = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
+            dW = torch.full((No, Ki), 1.0, device=dev)
+            db = torch.ones(No, device=dev)
+            k.wgrad(dY, X, dW, No, Ki, P, No, Ki, colsum_out=db, queue=q)
+            outs.append((dY, X, dW, db))
+        assert len(q.items) <= 35
+        q.flush()
+        torch.cuda.synchronize()
+        runs.append(outs)
+    for (dY, X, dW, db), (_, _, dW2, _) in zip(*runs):
+        close(dW, 1.0 + dY.float().t() @ X.float(), 2e-2, "slab wgrad")
+        close(db, 1.0 + dY.float().sum(0), 2e-2, "bias gradient beside slabs")
+        assert torch.equal(dW, dW2), "slab sums are added in a fixed order"
+    item = (k.SlabItem * 1)()
+    assert k._lib.pdmk_splitk_finish_group(C.cast(item, C.c_void_p), 1, None) == -1
+    assert k._lib.pdmk_splitk_finish_group(C.cast(item, C.c_void_p), 33, None) == -1
+
+
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
 def test_deferred_partial_reductions(dev, dn):
     """PartialQueue / pdmk_reduce_partials_group: GroupNorm and LayerNorm backward passes that leave their affine-gradient

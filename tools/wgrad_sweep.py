@@ -22,10 +22,18 @@ def gtime(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (5 * REP) * 1e3
 
+SLAB = "--slabs" in sys.argv      # splits store partial slabs (accumulate = 2) instead of adding with atomics; the finish is not timed
+
+
 def lin(P, No, Ki):
     dy = torch.randn(P, No, device=dev).to(dt); x = torch.randn(P, Ki, device=dev).to(dt)
     dw = torch.zeros(No, Ki, device=dev); db = torch.zeros(No, device=dev)
-    return f"lin P{P} {No}x{Ki}", 2.0 * P * No * Ki, lambda sk: k.gemm(dy, x, dw, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), colsum_out=db)
+    ws = torch.zeros(64 * No * Ki, device=dev) if SLAB else None
+    def run(sk):
+        if SLAB and sk > 1:
+            return k.gemm(dy, x, ws, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=2, colsum_out=db)
+        return k.gemm(dy, x, dw, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk, accumulate=(sk == 1), colsum_out=db)
+    return f"lin P{P} {No}x{Ki}", 2.0 * P * No * Ki, run
 
 def conv(B, H, Ci, Co):
     P = B * H * H
@@ -33,10 +41,11 @@ def conv(B, H, Ci, Co):
     dw = torch.zeros(Co, 9 * Ci, device=dev); db = torch.zeros(Co, device=dev)
     return f"conv B{B} {H}x{H} {Ci}->{Co}", 2.0 * P * Co * 9 * Ci, lambda sk: k.gemm(dy, x, dw, Co, 9 * Ci, P, Co, 0, 9 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=sk, accumulate=(sk == 1), conv=(B, H, H, Ci, H, H, 0, Ci), colsum_out=db)
 
-shapes = [lin(32768, 320, 320), lin(32768, 2560, 320), lin(32768, 320, 1280), lin(8192, 640, 640), lin(8192, 5120, 640), lin(2048, 1280, 1280), lin(2048, 1280, 5120),
+LIN_ONLY = SLAB
+shapes = [lin(32768, 320, 320), lin(32768, 960, 320), lin(32768, 2560, 320), lin(32768, 320, 1280), lin(8192, 640, 640), lin(8192, 5120, 640), lin(2048, 1280, 1280), lin(2048, 1280, 5120),
           conv(8, 64, 320, 320), conv(8, 32, 640, 640), conv(8, 16, 1280, 1280), conv(8, 8, 1280, 1280), conv(8, 32, 352, 608)]
 sks = [1, 2, 4, 8, 16, 32, 64]
-for name, fl, fn in shapes:
+for name, fl, fn in (shapes[:8] if LIN_ONLY else shapes):
     print(name)
     for cand in (0, 1, 2, 3, 4, 5):
         os.environ["PDMK_WGRAD_CFG"] = str(cand)

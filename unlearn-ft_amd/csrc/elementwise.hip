@@ -534,6 +534,25 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
+// Deferred sum of weight-gradient split-K slabs for up to PDMK_SLAB_GROUP_MAX weights in one launch:
+// dst[e] += sum_s ws[s * n + e], slabs added in a fixed order (bit-reproducible, no atomics); blockIdx.y = item.
+struct SlabGroup {
+    pdmk_slab_item it[PDMK_SLAB_GROUP_MAX];
+};
+__global__ void splitk_finish_group_kernel(SlabGroup gr) {
+    const pdmk_slab_item it = gr.it[blockIdx.y];
+    const long n4 = it.n / 4;
+    const float4* ws = reinterpret_cast<const float4*>(it.ws);
+    float4* dst = reinterpret_cast<float4*>(it.dst);
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        float4 a = dst[i];
+        for (int s = 0; s < it.nslab; ++s) {
+            const float4 v = ws[(long)s * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        dst[i] = a;
+    }
+}
 __global__ void sumsq_kernel(const float* __restrict__ x, long n, double* __restrict__ out, int slot) {
     float s = 0.f;
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) s += x[i] * x[i];
@@ -716,6 +735,23 @@ extern "C" int pdmk_adamw(float* p, float* g, float* m, float* v, int64_t n, con
     if (!p || !g || !m || !v || !lr || !bias_corr || n <= 0 || (n & 3)) return -1;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
                        beta1, beta2, eps, weight_decay, bias_corr, grad_scale, zero_grad, (bf16*)w_bf16);
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_splitk_finish_group(const pdmk_slab_item* items, int n_items, pdmk_stream s) {
+    if (!items || n_items <= 0 || n_items > PDMK_SLAB_GROUP_MAX) return -1;
+    SlabGroup gr;
+    long nmax = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const pdmk_slab_item& t = items[i];
+        if (!t.ws || !t.dst || t.n <= 0 || (t.n & 3) || t.nslab <= 0 || (((uintptr_t)t.ws | (uintptr_t)t.dst) & 15)) return -1;
+        gr.it[i] = t;
+        nmax = t.n > nmax ? t.n : nmax;
+    }
+    for (int i = n_items; i < PDMK_SLAB_GROUP_MAX; ++i) gr.it[i] = items[0];
+    long bx = (nmax / 4 + NT - 1) / NT;
+    bx = bx > 512 ? 512 : (bx < 1 ? 1 : bx);
+    hipLaunchKernelGGL(splitk_finish_group_kernel, dim3((unsigned)bx, n_items), dim3(NT), 0, (hipStream_t)s, gr);
     PDMK_CHECK_LAUNCH();
     return 0;
 }

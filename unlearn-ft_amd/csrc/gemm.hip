@@ -562,7 +562,10 @@ size_t g_scratch_bytes = 0;
 PlanKey make_key(const pdmk_gemm_args& g, int sk) {
     PlanKey k;
     const bool cv = g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV;
-    const int v[10] = {g.M, g.N, g.K, g.a_mode, g.b_mode, cv ? g.conv_mode : 100 * g.epilogue, cv ? g.conv_hi : 0,
+    // weight gradients whose splits go to slabs (accumulate = 2: plain stores, summed later by pdmk_splitk_finish_group) are
+    // planned apart from the ones that add with atomics: without the atomic traffic larger split factors win
+    const int slabw = (g.a_mode == PDMK_A_COLK && g.accumulate == 2) ? 1000 : 0;
+    const int v[10] = {g.M, g.N, g.K, g.a_mode, g.b_mode, (cv ? g.conv_mode : 100 * g.epilogue) + slabw, cv ? g.conv_hi : 0,
                        cv ? g.conv_wi : 0, cv ? g.conv_ci : 0, sk};
     memcpy(k.v, v, sizeof v);
     return k;
@@ -645,7 +648,11 @@ float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws,
         (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    return best * 1000.f / reps;
+    float us = best * 1000.f / reps;
+    // weight-gradient slabs: their sum is deferred to one grouped launch for many weights (pdmk_splitk_finish_group); it is
+    // priced here by its traffic at 4 TB/s instead of being launched per candidate
+    if (a.a_mode == PDMK_A_COLK && a.accumulate == 2) us += (float)(a.splitk + 1) * (float)a.M * (float)a.N * 4.f / 4.0e6f;
+    return us;
 }
 
 // best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().
@@ -664,7 +671,10 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     a.C2 = nullptr;                                  // tuning writes into scratch: the optional second output is left out
     if (a.colsum_out)
         a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(out2) + out_bytes);      // bias gradient -> scratch
-    if (g.a_mode == PDMK_A_COLK) a.C = ws;                                      // wgrad: fp32, atomics for sk > 1
+    if (g.a_mode == PDMK_A_COLK) {                                              // wgrad: fp32, atomics (or slabs) for sk > 1
+        a.C = ws;
+        if (g.accumulate == 2 && sk > 1) a.accumulate = 2;
+    }
     else if (sk > 1) { a.C = ws; a.out_f32 = 1; a.accumulate = 2; a.bias = nullptr; a.rowvec = nullptr; a.R = nullptr; }
     else a.C = out2;
     int best = -1;
@@ -898,4 +908,4 @@ extern "C" int pdmk_plan_clear(void) {
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 109; }
+extern "C" int pdmk_version(void) { return 110; }

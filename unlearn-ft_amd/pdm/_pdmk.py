@@ -57,6 +57,7 @@ _SIGS = {
     "pdmk_groupnorm_bwd_partial_dims": ([i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
     "pdmk_layernorm_bwd_partial_dims": ([i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
     "pdmk_reduce_partials_group": ([vp, i32, vp], i32),
+    "pdmk_splitk_finish_group": ([vp, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
@@ -272,9 +273,11 @@ def splitk_plan(A, B, M, N, K, lda, ldb, a_mode=A_ROWK, conv=None):
     return int(sk.value)
 
 
-def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None):
-    """Split-K factor for a weight-gradient GEMM dW[M,N] += dy[K,M]^T x[K,N] (both operands reduction-major)."""
+def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None, slabs=False):
+    """Split-K factor for a weight-gradient GEMM dW[M,N] += dy[K,M]^T x[K,N] (both operands reduction-major).
+    slabs: the splits will store partial slabs (accumulate = 2) instead of adding with atomics - planned apart."""
     g = GemmArgs()
+    g.accumulate = 2 if slabs else 0
     g.A, g.B = _p(dy), _p(x)
     g.M, g.N, g.K = M, N, K
     g.lda, g.ldb, g.ldc = lda, ldb, N
@@ -309,11 +312,55 @@ def splitk_finish(ws, Cout, M, N, ldc, nslab, *, bias=None, rowvec=None, R=None,
                                  int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")
 
 
-def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=None, macs=None):
+class SlabItem(C.Structure):
+    _fields_ = [("ws", vp), ("dst", vp), ("n", i64), ("nslab", i32), ("pad_", i32)]
+
+
+SLAB_GROUP_MAX = 32
+
+
+class SlabQueue:
+    """Deferred sums of weight-gradient split-K slabs (pdmk_splitk_finish_group): a weight gradient whose splits stored
+    their partials into a [sk][M][N] workspace is added into its gradient later, up to 32 weights per launch."""
+
+    def __init__(self, max_bytes=1 << 30):
+        self.items, self.bytes, self.max_bytes = [], 0, max_bytes
+
+    def add(self, ws, dW, n, nslab):
+        self.items.append((ws, dW, n, nslab))       # ws stays referenced until the flush
+        self.bytes += ws.numel() * 4
+
+    def full(self):
+        return len(self.items) >= SLAB_GROUP_MAX or self.bytes >= self.max_bytes
+
+    def flush(self):
+        while self.items:
+            chunk, self.items = self.items[:SLAB_GROUP_MAX], self.items[SLAB_GROUP_MAX:]
+            arr = (SlabItem * len(chunk))()
+            for a, (ws, dW, n, nslab) in zip(arr, chunk):
+                a.ws, a.dst, a.n, a.nslab = _p(ws), _p(dW), n, nslab
+            _chk(_lib.pdmk_splitk_finish_group(C.cast(arr, vp), len(chunk), _st()), "pdmk_splitk_finish_group")
+        self.bytes = 0
+
+
+def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=None, macs=None, queue=None):
     """dW[M, N] (fp32, row stride N) += dy[K, M]^T x[K, N] (3x3 gather of x for b_mode = B_COLK_CONV), split over the
-    pixel dimension K as the planner says.  Splits add into dW with fp32 atomics: measured against slabs + a finish pass
-    (which is what the forward / dgrad split-K uses) the extra launch per weight cost more than the atomics (-4 %)."""
-    sk = wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode, conv)
+    pixel dimension K as the planner says.  Without a queue the splits add into dW with fp32 atomics (a slab + finish pass
+    PER WEIGHT was measured 4 % slower for the step: one more launch per weight outweighs the atomics).  queue (a
+    SlabQueue): the splits store partial slabs with plain stores and the queue adds them into dW at its next flush, many
+    weights per launch - no atomics and no per-weight launch."""
+    if queue is not None and (M * N) % 4 == 0 and dW.is_contiguous():
+        sk = wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode, conv, slabs=True)
+        if sk > 1:
+            if queue.full():
+                queue.flush()
+            ws = torch.empty(sk * M * N, device=dy.device, dtype=torch.float32)
+            gemm(dy, x, ws, M, N, K, lda, ldb, N, a_mode=A_COLK, b_mode=b_mode, conv=conv, out_f32=True, splitk=sk,
+                 accumulate=2, dtype=dt(x), macs=macs, colsum_out=colsum_out)
+            queue.add(ws, dW, M * N, sk)
+            return
+    else:
+        sk = wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode, conv)
     gemm(dy, x, dW, M, N, K, lda, ldb, N, a_mode=A_COLK, b_mode=b_mode, conv=conv, out_f32=True, splitk=sk,
          accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
 

@@ -75,6 +75,8 @@ class UNetEngine:
         # GroupNorm / LayerNorm affine gradients: the second-stage reductions of a whole block run as one launch at the
         # block boundary (PDMK_DEFER_PARTIALS=0: one launch per layer, as before)
         self.partials = k.PartialQueue() if os.environ.get("PDMK_DEFER_PARTIALS", "1") != "0" else None
+        # Linear weight gradients: splits store partial slabs, one grouped launch adds them (PDMK_WGRAD_SLABS=0: atomics)
+        self.slabs = k.SlabQueue() if os.environ.get("PDMK_WGRAD_SLABS", "1") != "0" else None
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -134,6 +136,8 @@ class UNetEngine:
         cut) and at the end of backward()."""
         if self.partials is not None:
             self.partials.flush()
+        if self.slabs is not None:
+            self.slabs.flush()
 
     @staticmethod
     def _splitk(m_out, n_out, red, step):
@@ -210,7 +214,8 @@ class UNetEngine:
                 xt = x.t
                 # wgrad first (side stream if enabled), dgrad second: the two GEMMs of one layer can run side by side
                 self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), macs=lmacs,
-                                            colsum_out=P.g(bias) if bias else None),   # bias gradient fused in
+                                            colsum_out=P.g(bias) if bias else None,   # bias gradient fused in
+                                            queue=None if self.wgrad_async else self.slabs),
                             dy, xt)
                 if x.rg:
                     dx, acc = self._grad_into(x, M, Kp)
