@@ -49,7 +49,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
                                               int n0, int tw = 0, int img_w = 0) {
     auto row_of = [&](int l) { return TILE2D ? m0 + (l / tw) * img_w + (l % tw) : m0 + l; };
     constexpr int BN = 32 * NJ, IM = BM / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const bool first = blockIdx.y == 0;
     const bool slab = g.accumulate == 2;                 // split-K partials to slab blockIdx.y of a [splitk][M][ldc] workspace
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
     static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -333,8 +333,17 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
 
     int slot = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int ahead = min(STAGES - 2, kt1 - 1 - kt);            // younger K-steps already in flight
-        wait_vmcnt_dyn(ahead * ndma);
+        // younger K-steps already in flight: STAGES - 2 except in the last steps.  Immediate waits where the count is known at
+        // compile time (always for the two-slot rings, in the steady state for the deep ones, per wave class): the computed
+        // jump of wait_vmcnt_dyn and its scalar set-up are ~80 cycles per K-step
+        if (STAGES == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (kt + STAGES - 1 <= kt1) {
+            if ((NBLK_B % 8) == 0 || wave < (NBLK_B % 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB - 1)) : "memory");
+        } else {
+            wait_vmcnt_dyn(min(STAGES - 2, kt1 - 1 - kt) * ndma);
+        }
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
         const unsigned char* sa = smem + slot * SLOT;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * P_BYTES + BSTAGES * B_BYTES];
     unsigned char* const bring = smem + 2 * P_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -494,28 +503,48 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
         if (s < nsteps) issue_b(cb0 + s / 9, s % 9, s);
 
     const int n_ss = (BSTAGES - 2) * (nb_wave + 1) + 1;               // steady-state count of younger DMAs
-    int s = 0;
+    constexpr int N_SS_HI = (BSTAGES - 2) * (NB + 1) + 1;             // ... as immediates: waves with NB weight pieces per tile
+    constexpr int N_SS_LO = (BSTAGES - 2) * NB + 1;                   //     and (NBLK_B % 8 != 0) waves with NB - 1
+    int s = 0, slot_c = 0, slot_i = BSTAGES - 1;                      // step; ring slots of the tile read / issued next
     for (int cb = cb0; cb < cb1; ++cb) {
         const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
         // keep the 9 x IM x 2 fragment addresses from being hoisted out of this loop as invariants (72 VGPRs, spills)
 #pragma unroll
         for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
+        // interior channel blocks: every tap has a full ring behind it and a tile left to issue, so the event needs no
+        // run-time case analysis - an immediate s_waitcnt, tap / block of the next tile known at compile time, the patch
+        // piece chosen by a select.  (A scalar compare + branch costs ~40 cycles; the general path below has ~10 per tap,
+        // against 640 cycles of MFMA work per SIMD and tap for the 128-row tiles.)
+        const bool steady = cb > cb0 && cb + 1 < cb1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap, ++s) {
-            const bool tail = s + BSTAGES - 1 >= nsteps;
-            if (tail) wait_vmcnt_dyn(0);
-            else if (s <= BSTAGES - 2) wait_vmcnt_dyn((BSTAGES - 2 - s) * nb_wave + s * (nb_wave + 1));
-            else wait_vmcnt_dyn(n_ss);
-            __builtin_amdgcn_s_barrier();
-            if (!tail) {
-                const int sn = s + BSTAGES - 1;                       // weight tile to issue: step sn = (cbn, tapn)
-                const int cbn = cb0 + sn / 9, tapn = sn - (sn / 9) * 9;
-                issue_b(cbn, tapn, sn % BSTAGES);
-                // next block's patch, one piece per tap (surplus taps re-issue piece 0: identical bytes)
-                if (tap < NPW && (tap * 8 + wave) * 8 < prows) issue_piece(cb + 1, poff[tap < NPW ? tap : 0], tap);
-                else issue_piece(cb + 1, poff[0], 0);
+            if (steady) {
+                if ((NBLK_B % 8) == 0 || wave < (NBLK_B % 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_HI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_LO) : "memory");
+                __builtin_amdgcn_s_barrier();
+                constexpr int ahead = BSTAGES - 1;
+                issue_b(cb + ((tap + ahead) >= 9 ? 1 : 0), (tap + ahead) % 9, slot_i);
+                const bool own = tap < NPW && (tap * 8 + wave) * 8 < prows;
+                issue_piece(cb + 1, own ? poff[tap < NPW ? tap : 0] : poff[0], own ? tap : 0);
+                slot_i = slot_i + 1 == BSTAGES ? 0 : slot_i + 1;
+            } else {
+                const bool tail = s + BSTAGES - 1 >= nsteps;
+                if (tail) wait_vmcnt_dyn(0);
+                else if (s <= BSTAGES - 2) wait_vmcnt_dyn((BSTAGES - 2 - s) * nb_wave + s * (nb_wave + 1));
+                else wait_vmcnt_dyn(n_ss);
+                __builtin_amdgcn_s_barrier();
+                if (!tail) {
+                    const int sn = s + BSTAGES - 1;                   // weight tile to issue: step sn = (cbn, tapn)
+                    const int cbn = cb0 + sn / 9, tapn = sn - (sn / 9) * 9;
+                    issue_b(cbn, tapn, slot_i);
+                    slot_i = slot_i + 1 == BSTAGES ? 0 : slot_i + 1;
+                    // next block's patch, one piece per tap (surplus taps re-issue piece 0: identical bytes)
+                    if (tap < NPW && (tap * 8 + wave) * 8 < prows) issue_piece(cb + 1, poff[tap < NPW ? tap : 0], tap);
+                    else issue_piece(cb + 1, poff[0], 0);
+                }
             }
-            const unsigned char* sb = bring + (s % BSTAGES) * B_BYTES;
+            const unsigned char* sb = bring + slot_c * B_BYTES;
+            slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
             const int toff = (tap / 3) * W2 + (tap % 3);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -561,7 +590,7 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     static_assert(64 * (BN + 4) * 4 <= STAGES * SLOT, "epilogue staging");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -670,8 +699,9 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
 
     int slot = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int ahead = min(STAGES - 2, kt1 - 1 - kt);
-        wait_vmcnt_dyn(ahead * (PA + PB));
+        if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (kt + STAGES - 1 <= kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (PA + PB)) : "memory");
+        else wait_vmcnt_dyn(min(STAGES - 2, kt1 - 1 - kt) * (PA + PB));
         __builtin_amdgcn_s_barrier();
         if (kt + STAGES - 1 < kt1) issue(kt + STAGES - 1, slot == 0 ? STAGES - 1 : slot - 1);
         const unsigned char* sa = smem + slot * SLOT;
@@ -863,7 +893,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     static_assert((IMW == 2 || IMW == 4) && BM * 68 * 4 <= STAGES * SLOT, "epilogue staging");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 2, wn = wave & 3;
     const int Ci = g.conv_ci, H = g.conv_hi, W = g.conv_wi, HW = H * W;
     const int nct = (Ci + 63) / 64;
