@@ -11,7 +11,7 @@ import collections, csv, glob, json, re, sys
 def symbol(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     n = re.sub(r"\(.*$", "", n).strip()
-    if "igemm" not in n and "wgrad_ring" not in n and "conv_halo" not in n and "conv_wgrad_halo" not in n:
+    if "igemm" not in n and "wgrad_ring" not in n and "conv_halo" not in n and "conv_wgrad_halo" not in n and "rowblock" not in n:
         return None
     return n
 
