@@ -14,6 +14,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef PDMK_HALO_PAIRS
+#define PDMK_HALO_PAIRS 1     // halo conv, rings of >= 4 slots: two taps per barrier (0: one, as in round 1)
+#endif
+
 namespace pdmk_ring {
 
 constexpr int BK = 64, NT = 512;
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i * 8 + wave < NBLK_B) {
-                const unsigned vb = (b_base[i] != OOB && ch < Ci) ? b_base[i] + koff : OOB;
+                const unsigned vb = (b_base[i] != OOB && ch < Ci && cb < cb1) ? b_base[i] + koff : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sb + (i * 8 + wave) * 1024), 16, (int)vb, 0, 0, 0);
             }
         }
@@ -493,76 +497,135 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const unsigned fch0 = (unsigned)((fg ^ fsw) * 16), fch1 = (unsigned)(((4 + fg) ^ fsw) * 16);
     const unsigned b_row = (unsigned)(wn * (16 * NJ) + fr) * 128u;
 
-    // ---- prologue: the first patch, then BSTAGES-1 weight tiles
-    const int nsteps = cb1 > cb0 ? (cb1 - cb0) * 9 : 0;
+    // one tap: 2 x (IM x NJ) MFMAs out of the patch (shifted rows) and one weight tile
+    auto tap_compute = [&](const unsigned char* pbuf, const unsigned char* sb, int tap) __attribute__((always_inline)) {
+        const int toff = (tap / 3) * W2 + (tap % 3);
 #pragma unroll
-    for (int j = 0; j < NPW; ++j)
-        if (nsteps > 0 && (j * 8 + wave) * 8 < prows) issue_piece(cb0, poff[j], j);
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[IM], bf[NJ];
 #pragma unroll
-    for (int s = 0; s < BSTAGES - 1; ++s)
-        if (s < nsteps) issue_b(cb0 + s / 9, s % 9, s);
+            for (int i = 0; i < IM; ++i) {
+                const int prow = prow0[i] + toff;
+                af[i] = *reinterpret_cast<const bf16x8*>(pbuf + prow * 128 + (((fg + 4 * kk) ^ (prow & 7)) * 16));
+            }
+            const unsigned fch = kk ? fch1 : fch0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // no cross-tap code motion: keeps fragment live ranges to one tap
+    };
 
-    const int n_ss = (BSTAGES - 2) * (nb_wave + 1) + 1;               // steady-state count of younger DMAs
-    constexpr int N_SS_HI = (BSTAGES - 2) * (NB + 1) + 1;             // ... as immediates: waves with NB weight pieces per tile
-    constexpr int N_SS_LO = (BSTAGES - 2) * NB + 1;                   //     and (NBLK_B % 8 != 0) waves with NB - 1
-    int s = 0, slot_c = 0, slot_i = BSTAGES - 1;                      // step; ring slots of the tile read / issued next
-    for (int cb = cb0; cb < cb1; ++cb) {
-        const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
-        // keep the 9 x IM x 2 fragment addresses from being hoisted out of this loop as invariants (72 VGPRs, spills)
+    const int nsteps = cb1 > cb0 ? (cb1 - cb0) * 9 : 0;
+    if (BSTAGES >= 4 && PDMK_HALO_PAIRS) {
+        // ---- two taps per barrier (rings of >= 4 slots: the 128-row tiles).  A K-step of an 8-wave workgroup has ~480 cycles
+        // of fixed cost (wait + barrier rendezvous + restart of the MFMA stream) next to 640 cycles of MFMA work
+        // per SIMD and tap for these tiles; events (0,1) (2,3) (4,5) (6,7) (8) of a channel block halve the number of barriers.
+        // An event waits for EVERYTHING in flight (its two weight tiles and the patch pieces issued with them, one event ago:
+        // plain vmcnt(0), no counting), then issues the next event's tiles into the slots behind its own and two pieces of the
+        // next block's patch; nothing in the loop depends on where in the sequence it is (tiles / pieces past the end read out
+        // of range), so the body has no branches.
 #pragma unroll
-        for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
-        // interior channel blocks: every tap has a full ring behind it and a tile left to issue, so the event needs no
-        // run-time case analysis - an immediate s_waitcnt, tap / block of the next tile known at compile time, the patch
-        // piece chosen by a select.  (A scalar compare + branch costs ~40 cycles; the general path below has ~10 per tap,
-        // against 640 cycles of MFMA work per SIMD and tap for the 128-row tiles.)
-        const bool steady = cb > cb0 && cb + 1 < cb1;
+        for (int j = 0; j < NPW; ++j) {
+            const bool own = (j * 8 + wave) * 8 < prows;              // surplus pieces re-issue piece 0 (identical bytes, inside the buffer)
+            issue_piece(nsteps > 0 ? cb0 : cb1, own ? poff[j] : poff[0], own ? j : 0);
+        }
+        issue_b(nsteps > 0 ? cb0 : cb1, 0, 0);
+        issue_b(nsteps > 0 ? cb0 : cb1, 1, 1);
+        int slot_c = 0;
+        for (int cb = cb0; cb < cb1; ++cb) {
+            const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            if (steady) {
-                if ((NBLK_B % 8) == 0 || wave < (NBLK_B % 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_HI) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_LO) : "memory");
+            for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                const int t0 = 2 * e, ne = e < 4 ? 2 : 1;                 // this event's taps
+                const int nn = e == 3 ? 1 : 2;                            // taps of the NEXT event: (8) after (6,7), else two
+                const int cbn = e == 4 ? cb + 1 : cb, tn0 = e == 4 ? 0 : t0 + 2;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                constexpr int ahead = BSTAGES - 1;
-                issue_b(cb + ((tap + ahead) >= 9 ? 1 : 0), (tap + ahead) % 9, slot_i);
-                const bool own = tap < NPW && (tap * 8 + wave) * 8 < prows;
-                issue_piece(cb + 1, own ? poff[tap < NPW ? tap : 0] : poff[0], own ? tap : 0);
-                slot_i = slot_i + 1 == BSTAGES ? 0 : slot_i + 1;
-            } else {
-                const bool tail = s + BSTAGES - 1 >= nsteps;
-                if (tail) wait_vmcnt_dyn(0);
-                else if (s <= BSTAGES - 2) wait_vmcnt_dyn((BSTAGES - 2 - s) * nb_wave + s * (nb_wave + 1));
-                else wait_vmcnt_dyn(n_ss);
-                __builtin_amdgcn_s_barrier();
-                if (!tail) {
-                    const int sn = s + BSTAGES - 1;                   // weight tile to issue: step sn = (cbn, tapn)
-                    const int cbn = cb0 + sn / 9, tapn = sn - (sn / 9) * 9;
-                    issue_b(cbn, tapn, slot_i);
+                int sl = slot_c + ne;
+                sl = sl >= BSTAGES ? sl - BSTAGES : sl;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u < nn) {
+                        issue_b(cbn, tn0 + u, sl);
+                        sl = sl + 1 == BSTAGES ? 0 : sl + 1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u < ne) {
+                        const int t = t0 + u;
+                        const bool own = t < NPW && (t * 8 + wave) * 8 < prows;
+                        issue_piece(cb + 1, own ? poff[t < NPW ? t : 0] : poff[0], own ? t : 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u < ne) {
+                        tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + u);
+                        slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
+                    }
+                }
+            }
+        }
+    } else {
+        // ---- prologue: the first patch, then BSTAGES-1 weight tiles
+    #pragma unroll
+        for (int j = 0; j < NPW; ++j)
+            if (nsteps > 0 && (j * 8 + wave) * 8 < prows) issue_piece(cb0, poff[j], j);
+    #pragma unroll
+        for (int s = 0; s < BSTAGES - 1; ++s)
+            if (s < nsteps) issue_b(cb0 + s / 9, s % 9, s);
+
+        const int n_ss = (BSTAGES - 2) * (nb_wave + 1) + 1;               // steady-state count of younger DMAs
+        constexpr int N_SS_HI = (BSTAGES - 2) * (NB + 1) + 1;             // ... as immediates: waves with NB weight pieces per tile
+        constexpr int N_SS_LO = (BSTAGES - 2) * NB + 1;                   //     and (NBLK_B % 8 != 0) waves with NB - 1
+        int s = 0, slot_c = 0, slot_i = BSTAGES - 1;                      // step; ring slots of the tile read / issued next
+        for (int cb = cb0; cb < cb1; ++cb) {
+            const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
+            // keep the 9 x IM x 2 fragment addresses from being hoisted out of this loop as invariants (72 VGPRs, spills)
+    #pragma unroll
+            for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
+            // interior channel blocks: every tap has a full ring behind it and a tile left to issue, so the event needs no
+            // run-time case analysis - an immediate s_waitcnt, tap / block of the next tile known at compile time, the patch
+            // piece chosen by a select.  (A scalar compare + branch costs ~40 cycles; the general path below has ~10 per tap,
+            // against 640 cycles of MFMA work per SIMD and tap for the 128-row tiles.)
+            const bool steady = cb > cb0 && cb + 1 < cb1;
+    #pragma unroll
+            for (int tap = 0; tap < 9; ++tap, ++s) {
+                if (steady) {
+                    if ((NBLK_B % 8) == 0 || wave < (NBLK_B % 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_HI) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_SS_LO) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    constexpr int ahead = BSTAGES - 1;
+                    issue_b(cb + ((tap + ahead) >= 9 ? 1 : 0), (tap + ahead) % 9, slot_i);
+                    const bool own = tap < NPW && (tap * 8 + wave) * 8 < prows;
+                    issue_piece(cb + 1, own ? poff[tap < NPW ? tap : 0] : poff[0], own ? tap : 0);
                     slot_i = slot_i + 1 == BSTAGES ? 0 : slot_i + 1;
-                    // next block's patch, one piece per tap (surplus taps re-issue piece 0: identical bytes)
-                    if (tap < NPW && (tap * 8 + wave) * 8 < prows) issue_piece(cb + 1, poff[tap < NPW ? tap : 0], tap);
-                    else issue_piece(cb + 1, poff[0], 0);
+                } else {
+                    const bool tail = s + BSTAGES - 1 >= nsteps;
+                    if (tail) wait_vmcnt_dyn(0);
+                    else if (s <= BSTAGES - 2) wait_vmcnt_dyn((BSTAGES - 2 - s) * nb_wave + s * (nb_wave + 1));
+                    else wait_vmcnt_dyn(n_ss);
+                    __builtin_amdgcn_s_barrier();
+                    if (!tail) {
+                        const int sn = s + BSTAGES - 1;                   // weight tile to issue: step sn = (cbn, tapn)
+                        const int cbn = cb0 + sn / 9, tapn = sn - (sn / 9) * 9;
+                        issue_b(cbn, tapn, slot_i);
+                        slot_i = slot_i + 1 == BSTAGES ? 0 : slot_i + 1;
+                        // next block's patch, one piece per tap (surplus taps re-issue piece 0: identical bytes)
+                        if (tap < NPW && (tap * 8 + wave) * 8 < prows) issue_piece(cb + 1, poff[tap < NPW ? tap : 0], tap);
+                        else issue_piece(cb + 1, poff[0], 0);
+                    }
                 }
+                tap_compute(pbuf, bring + slot_c * B_BYTES, tap);
+                slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
             }
-            const unsigned char* sb = bring + slot_c * B_BYTES;
-            slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
-            const int toff = (tap / 3) * W2 + (tap % 3);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 af[IM], bf[NJ];
-#pragma unroll
-                for (int i = 0; i < IM; ++i) {
-                    const int prow = prow0[i] + toff;
-                    af[i] = *reinterpret_cast<const bf16x8*>(pbuf + prow * 128 + (((fg + 4 * kk) ^ (prow & 7)) * 16));
-                }
-                const unsigned fch = kk ? fch1 : fch0;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
-#pragma unroll
-                for (int i = 0; i < IM; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
-            }
-            __builtin_amdgcn_sched_barrier(0);        // no cross-tap code motion: keeps fragment live ranges to one tap
         }
     }
     if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
