@@ -211,7 +211,7 @@ def test_layernorm(dev, dn, C, M):
     close(dbt, gb, TOL[dn] * 2, "ln dbeta")
 
 
-@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 5])
+@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 5, 6, 7])
 def test_wgrad_slabs_and_grouped_finish(dev, force_cfg, cand):
     """Weight gradients whose splits store partial slabs (accumulate = 2 on the reduction-major path) and
     pdmk_splitk_finish_group adding the slabs of many weights in one launch: equal to fp32 math, and bit-reproducible
@@ -243,6 +243,21 @@ def test_wgrad_slabs_and_grouped_finish(dev, force_cfg, cand):
         close(dW, 1.0 + dY.float().t() @ X.float(), 2e-2, "slab wgrad")
         close(db, 1.0 + dY.float().sum(0), 2e-2, "bias gradient beside slabs")
         assert torch.equal(dW, dW2), "slab sums are added in a fixed order"
+    # 3x3 conv weight gradients through the same queue (the halo kernels, candidates 6 / 7, store slabs too)
+    q = k.SlabQueue()
+    for Bn, Hs, Ci, Co in ((2, 32, 64, 96), (4, 16, 96, 160), (1, 64, 32, 64)):
+        x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+        w = torch.zeros(Co, Ci, 3, 3, device=dev, requires_grad=True)
+        y = F.conv2d(x.float().permute(0, 3, 1, 2), w, padding=1)
+        dy = rnd((Bn, Hs, Hs, Co), dev, dt)
+        (gw,) = torch.autograd.grad(y, w, dy.float().permute(0, 3, 1, 2))
+        P = Bn * Hs * Hs
+        dW = torch.full((Co, 9 * Ci), 1.0, device=dev)
+        db = torch.ones(Co, device=dev)
+        k.wgrad(dy, x, dW, Co, 9 * Ci, P, Co, 0, b_mode=k.B_COLK_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci), colsum_out=db, queue=q)
+        q.flush()
+        close(dW, 1.0 + conv_w_pack(gw), 2e-2, f"slab conv wgrad B{Bn} {Hs}x{Hs} {Ci}->{Co}")
+        close(db, 1.0 + dy.float().sum(dim=(0, 1, 2)), 2e-2, "conv bias gradient beside slabs")
     item = (k.SlabItem * 1)()
     assert k._lib.pdmk_splitk_finish_group(C.cast(item, C.c_void_p), 1, None) == -1
     assert k._lib.pdmk_splitk_finish_group(C.cast(item, C.c_void_p), 33, None) == -1

@@ -965,7 +965,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     const int nblk = (g.K + PX - 1) / PX;
     const int per = (nblk + gridDim.y - 1) / gridDim.y;
     const int kb0 = blockIdx.y * per, kb1 = min(nblk, kb0 + per);
-    if (kb0 >= kb1) return;
+    if (kb0 >= kb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     const int rimg = HW >= PX ? PX / W : H;                           // rows of an image inside a pixel block
     // patch row stride padded to a multiple of 8 pixels: (row + ky * W2) & 7 == row & 7, so the swizzle term of a tap
@@ -1115,8 +1115,12 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     // ---- epilogue: one tap at a time through a [BM][68] fp32 staging image; a wave writes BM/8 rows of 64 floats
     constexpr int SROW = 68;
     float* stage = reinterpret_cast<float*>(smem);
-    float* Cf = reinterpret_cast<float*>(g.C);
-    const bool atomic = gridDim.y > 1, acc1 = g.accumulate == 1;
+    // accumulate = 2: split z stores its partial tile into slab z of a [splits][M][ldc] workspace with plain stores (summed later
+    // by pdmk_splitk_finish_group); else several splits add with fp32 atomics - ~180 KB per workgroup at ~5 GB/s per CU, which
+    // is what bounded this kernel
+    const bool slab = g.accumulate == 2;
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
+    const bool atomic = gridDim.y > 1 && !slab, acc1 = g.accumulate == 1;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -1142,7 +1146,7 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
 
 static bool wgrad_halo_ok(const pdmk_gemm_args& g) {
     if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode != PDMK_B_COLK_CONV || !g.out_f32) return false;
-    if (g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi || g.accumulate == 2 || g.alpha != 1.0f) return false;
+    if (g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi || g.alpha != 1.0f) return false;
     if ((g.conv_ci % 8) || (g.conv_ld % 8) || (g.lda % 8) || (g.M % 8) || g.N != 9 * g.conv_ci || g.conv_wi < 4) return false;
     const int H = g.conv_hi, W = g.conv_wi, HW = H * W, W2 = (W + 2 + 7) & ~7;
     if (HW >= 128) return (HW % 128) == 0 && (128 % W) == 0 && (128 / W + 2) * W2 <= 288;

@@ -77,6 +77,9 @@ class UNetEngine:
         self.partials = k.PartialQueue() if os.environ.get("PDMK_DEFER_PARTIALS", "1") != "0" else None
         # Linear weight gradients: splits store partial slabs, one grouped launch adds them (PDMK_WGRAD_SLABS=0: atomics)
         self.slabs = k.SlabQueue() if os.environ.get("PDMK_WGRAD_SLABS", "1") != "0" else None
+        # ... the 3x3 conv weight gradients too (PDMK_WGRAD_SLABS_CONV=1): measured, no gain (43.3 vs 43.6 ms per main step:
+        # their slabs are sk x 4-60 MB each), so they keep the atomics
+        self.conv_slabs = os.environ.get("PDMK_WGRAD_SLABS_CONV", "0") == "1"
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -265,7 +268,8 @@ class UNetEngine:
                 xt = x.t
                 self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, b_mode=k.B_COLK_CONV,
                                             conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), macs=lmacs,
-                                            colsum_out=None if rowvec is not None else P.g(bias)),
+                                            colsum_out=None if rowvec is not None else P.g(bias),
+                                            queue=None if (self.wgrad_async or not self.conv_slabs) else self.slabs),
                             dy, xt)
                 if x.rg:
                     if mode == 2:
