@@ -26,9 +26,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 constexpr unsigned OOB = 0x80000000u;
 
+#ifndef PDMK_ATTN_KVB
+#define PDMK_ATTN_KVB 64      // streamed K/V (forward, dq) and Q/dO (dk/dv) rows per block and barrier pair
+#endif
 template <typename T> struct ACfg;
 template <> struct ACfg<bf16> {
-    static constexpr int CH = 8, RS = 64, KVB = 64;   // RS: LDS row stride of a [rows][64] tile; KVB: streamed rows
+    static constexpr int CH = 8, RS = 64, KVB = PDMK_ATTN_KVB;   // RS: LDS row stride of a [rows][64] tile; KVB: streamed rows
 };
 template <> struct ACfg<float> {
     static constexpr int CH = 4, RS = 68, KVB = 32;
