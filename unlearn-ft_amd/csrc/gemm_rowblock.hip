@@ -33,6 +33,9 @@
 #ifndef PDMK_RB_STORE_AUX
 #define PDMK_RB_STORE_AUX (PDMK_NT_STORES ? 2 : 0)   // cache policy of the output stores: 2 = nt (streaming; common.h st_stream), 16 = sc1 (write-through: measured slower)
 #endif
+#ifndef PDMK_RB_DEFER_GEGLU
+#define PDMK_RB_DEFER_GEGLU 0   // 1: MODE 2 parks bf16 accumulators and defers its (VALU-heavy, ~8000 cycles per n-tile) epilogue instead of pipelining fragments: measured +-0 (107.3 vs 105.8 us at N = 2560)
+#endif
 #ifndef PDMK_RB_DEFER
 #define PDMK_RB_DEFER 0      // deferred epilogue halves: 40 more live registers (spills beside the pipelined fragments) for ~5 %
 #endif
@@ -344,7 +347,10 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
     // step before (the barrier of step q guarantees stage q + 1 has landed).  The wave's DMA pieces of the stage DEP ahead go
     // out either in the first or in the second half of the MFMA stream (EARLY: one uniform branch per step selects the body):
     // SIMD partners w / w + 4 and neighbouring SIMDs differ, so that not all eight waves sit in the memory pipe together
-    constexpr bool PIPE = MODE != 1;                                 // MODE 1 keeps 24 registers of prefetched addend instead
+    // 40 registers go either to the pipelined kk = 0 fragments (MODE 0), to the prefetched addend (MODE 1, 24 of them) or to the
+    // parked accumulators of a deferred epilogue (MODE 2: the GEGLU epilogue is ~8000 cycles of VALU work per n-tile - erf-GELU on
+    // 10 240 elements - which rides on the next n-tile's steps beside the SIMD partner's MFMAs instead of stalling the barrier)
+    constexpr bool PIPE = MODE == 0 || (MODE == 2 && !PDMK_RB_DEFER_GEGLU);
     bf16x8 f0[NJ];                                                   // kk = 0 fragments of the stage about to be multiplied
     auto compute = [&](int slot, int kt, bool EARLY) __attribute__((always_inline)) {
         const unsigned char* sb = ring + slot * B_BYTES;
@@ -374,12 +380,53 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
         }
     };
 
-    constexpr bool DEFER = PDMK_RB_DEFER && MODE != 1 && 2 * IM <= NKA;   // MODE 1: the addend registers belong to one n-tile at a time
-    f32x4 old[IM][NJ];                                               // accumulators of the n-tile whose epilogue is deferred
+    constexpr bool DEFER = (PDMK_RB_DEFER || (MODE == 2 && PDMK_RB_DEFER_GEGLU)) && MODE != 1 && 2 * IM <= NKA;   // MODE 1: the addend registers belong to one n-tile at a time
+    // accumulators of the n-tile whose epilogue is deferred.  MODE 2 parks bf16(alpha * acc + bias) - exactly the values its
+    // epilogue rounds to anyway - in half the registers
+    typedef typename std::conditional<MODE == 2, bf16x4, f32x4>::type park_t;
+    park_t old[IM][NJ];
 #pragma unroll
     for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) old[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) old[i][j] = park_t{};
+    auto park = [&](int t) __attribute__((always_inline)) {
+        const int n0 = t * BN + wn * WCOLS;
+#pragma unroll
+        for (int i = 0; i < IM; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (MODE == 2) {
+                    f32x4 v = acc[i][j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= g.alpha;
+                    if (g.bias) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + n0 + j * 16 + (lane >> 4) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += b4[r];
+                    }
+                    bf16x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (bf16)v[r];
+                    old[i][j] = h;
+                } else {
+                    old[i][j] = acc[i][j];
+                }
+                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    };
+    auto epi_write_parked = [&](int i, int t) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (float)old[i][j][r];
+                *reinterpret_cast<f32x4*>(stage + (lane & 15) * SROW + j * 16 + (lane >> 4) * 4) = v;
+            }
+        } else {
+            epi_write(old, i, t);
+        }
+    };
     bool pend = false;
     int sc = 0;                                                      // slot being consumed
     wait_vmcnt_dyn(issued - mk[0]);                                  // stage 0, and its kk = 0 fragments
@@ -402,14 +449,11 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
             sc = sc + 1 == BST ? 0 : sc + 1;
             if (DEFER && pend && kin < 2 * IM) {                     // a half of the previous n-tile's epilogue
                 if (kin & 1) epi_read(kin >> 1, t - 1);
-                else epi_write(old, kin >> 1, t - 1);
+                else epi_write_parked(kin >> 1, t - 1);
             }
         }
         if (DEFER && t + 1 < t1) {
-#pragma unroll
-            for (int i = 0; i < IM; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) { old[i][j] = acc[i][j]; acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            park(t);
             pend = true;
         } else {
             epilogue_now(t);
