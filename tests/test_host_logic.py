@@ -50,6 +50,42 @@ def test_workspace_queries_and_plan_file_roundtrip(tmp_path):
     assert k.plan_size() == 0
 
 
+def test_partial_dims_queries_and_deferred_queues_chunk_by_32(monkeypatch):
+    """The geometry queries of the deferred reductions answer without a GPU and agree with the workspace queries; the two
+    queues hand the library at most 32 items per launch, keep their slabs alive until then, and the slab queue reports
+    itself full by count or by bytes (host logic only: the entry points are replaced by recorders)."""
+    import ctypes as C
+    from pdm import _pdmk as k
+    nblk, n = k._dims(k._lib.pdmk_layernorm_bwd_partial_dims, 32768, 320)
+    assert (nblk, n) == (1024, 320) and nblk * 2 * n * 4 <= k._lib.pdmk_layernorm_bwd_part_workspace_bytes(32768, 320)
+    nblk, n = k._dims(k._lib.pdmk_groupnorm_bwd_partial_dims, 8, 4096, 320, 32, 10, k.BF16)
+    assert n == 320 and 0 < nblk * 2 * n * 4 <= k._lib.pdmk_groupnorm_bwd_part_workspace_bytes(32, 10)
+    a, b = C.c_int32(), C.c_int32()
+    assert k._lib.pdmk_layernorm_bwd_partial_dims(0, 320, C.byref(a), C.byref(b)) == -1
+    assert k._lib.pdmk_groupnorm_bwd_partial_dims(8, 64, 321, 32, 10, k.BF16, C.byref(a), C.byref(b)) == -1     # C % 8
+    calls = []
+    monkeypatch.setattr(k, "_st", lambda: None)
+    monkeypatch.setattr(k._lib, "pdmk_reduce_partials_group", lambda arr, cnt, st: calls.append(("p", cnt)) or 0)
+    monkeypatch.setattr(k._lib, "pdmk_splitk_finish_group", lambda arr, cnt, st: calls.append(("s", cnt)) or 0)
+    g0, g1 = torch.zeros(8), torch.zeros(8)
+    q = k.PartialQueue()
+    slabs = [q.slab(torch.device("cpu"), 4, 8, g0, g1) for _ in range(70)]
+    assert calls == [("p", 32), ("p", 32)] and len(q.items) == 6 and all(s.numel() == 4 * 2 * 8 for s in slabs)
+    q.flush()
+    assert calls[-1] == ("p", 6) and not q.items
+    calls.clear()
+    sq = k.SlabQueue(max_bytes=1000)
+    assert not sq.full()
+    sq.add(torch.zeros(200), g0, 8, 25)
+    assert not sq.full()
+    sq.add(torch.zeros(100), g0, 8, 12)
+    assert sq.full()                       # 1200 bytes queued
+    for _ in range(40):
+        sq.add(torch.zeros(4), g0, 4, 1)
+    sq.flush()
+    assert calls == [("s", 32), ("s", 10)] and sq.bytes == 0 and not sq.items
+
+
 def test_structure_matches_oracle_and_reference_sizes():
     from pdm.models.unet import spec
     for mk, omk in ((spec.UNetConfig.tiny, OCfg.tiny), (spec.UNetConfig.sd21, OCfg.sd21)):
