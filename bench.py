@@ -118,7 +118,9 @@ def cpu_baseline(budget, latent, tiny, full=False):
     first = run(best_n, 3 if full else 1, 5 if full else 3)
     out = {"value": first["images_per_s_bilevel"], "unit": "images/s", "cores": best_n, "kind": "port",
            "cpu_model": model, "host_threads": all_cores,
-           "sample": f"bilevel blend 10/(10 t_main + t_upper) of the pure-torch CPU oracle at B=1, {latent}x{latent} latent, fp32, "
+           "sample": f"[bounded sample; BASELINE.md 3's full 3 + 5 protocol at every thread count is kept in "
+                     f"profiles/r02_cpu_baseline_full.json (--cpu_baseline_full)] "
+                     f"bilevel blend 10/(10 t_main + t_upper) of the pure-torch CPU oracle at B=1, {latent}x{latent} latent, fp32, "
                      f"budget-{budget} student + dense teacher: {first['warmup']} warm-up + {first['timed']} timed main steps "
                      f"(median {first['main_step_s_median']} s) + 1 upper step ({first['upper_step_s']} s) at {best_n} threads = the "
                      f"fastest of a 1-step scan over {sorted(scan)} threads ({all_cores}-thread host)",
@@ -269,9 +271,8 @@ def main():
             main_iter(i)
             if (i + 1) % a.upper_freq == 0:
                 upper_iter(i)
-        else:      # the NEXT main batches are announced: one dense (frozen) teacher forward serves a group of them
-            ups = [data[(i + j) % nb] for j in range(1, max(2, graphs.tgroup))]
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=[(q["lat"], q["noise"], q["t"], q["ehs"]) for q in ups])
+        else:
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
             if (i + 1) % a.upper_freq == 0:
                 graphs.upper(u["lat"], u["noise"], u["t"], u["ehs"], empty)
 
@@ -309,16 +310,14 @@ def main():
             if graphs is not None:
                 d0 = data[0]
                 tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
-                nmb = 2 * max(2, graphs.tgroup)          # whole teacher groups: the (amortised) teacher pass is in the average
-                extras["ms_main_step"] = round(timed(lambda j: graphs.main(
-                    *tup(data[j % nb]), nxt=[tup(data[(j + q) % nb]) for q in range(1, max(2, graphs.tgroup))]), nmb) * 1e3, 2)
+                extras["ms_main_step"] = round(timed(lambda j: graphs.main(*tup(data[j % nb])), 4) * 1e3, 2)
                 extras["ms_upper_step"] = round(timed(lambda j: graphs.upper(d0["lat"], d0["noise"], d0["t"], d0["ehs"], empty), 2) * 1e3, 2)
                 st.defer_reduce = False
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
-        extras["teacher_prefetch"] = bool(graphs is not None and graphs.prefetch)
-        extras["teacher_group"] = int(graphs.tgroup) if graphs is not None else 1
+        if graphs is not None:
+            extras["graphs_per_main_step"] = len(graphs.g_main.all())
         if world == 1 and not a.no_vae and not a.tiny:
             # SURVEY 8f N1, NOT part of `value` (SURVEY 8d keeps the VAE off the timed path): what a pixel_values batch adds
             # in front of every step - vae.encode(pixels).latent_dist.sample() * 0.18215 (trainer.py:2405-2406)
@@ -393,6 +392,7 @@ def main():
             pk = (2500e12 if a.dtype == "bf16" else 157.3e12)
             t_m = t_h = t_r = t_meas = t_i = t_3 = 0.0
             n_h = n_i = 0
+            b_tot = 0.0
             for kind, flops, e0, e1, (M, N, K, sk) in entries:
                 conv_a, wg = kind[1] == 1, kind[1] == 2
                 if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
@@ -400,6 +400,7 @@ def main():
                 else:
                     byts = esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
                 tm, th = 2.0 * M * N * K / pk, byts / 8e12
+                b_tot += byts
                 # third side: what a CU can take in from L2 into LDS (~70 GB/s per CU, 18 TB/s chip-wide: MI355X_MICROARCH.md
                 # "Indexed rows: gather into LDS", tools/small_gemm_sweep.py).  An output tile BM x BN needs (BM + BN) K
                 # operand elements whatever the kernel (a halo-staged 3x3 conv reads its activation patch once per 9 taps);
@@ -419,6 +420,7 @@ def main():
             return {"mfma_floor_ms": round(t_m * 1e3, 3), "hbm_floor_ms": round(t_h * 1e3, 3),
                     "roofline_floor_ms": round(t_r * 1e3, 3), "measured_ms": round(t_meas * 1e3, 3),
                     "frac": round(t_r / t_meas, 4), "launches": len(entries), "hbm_bound_launches": int(n_h),
+                    "algorithmic_bytes_per_launch": round(b_tot / max(len(entries), 1)),
                     "l2_intake_floor_ms": round(t_i * 1e3, 3), "three_sided_floor_ms": round(t_3 * 1e3, 3),
                     "three_sided_frac": round(t_3 / t_meas, 4), "intake_bound_launches": int(n_i)}
         peak = 2500.0 if a.dtype == "bf16" else 157.3
@@ -432,16 +434,20 @@ def main():
             rec = json.load(open(tfile)).get(sym(dom[0]) if dom[0][3] > 0 else legacy_sym.get(dom[0][1:3], ""))
             traffic = rec and round(rec["hbm_bytes_per_launch"])
         top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]
+        dom_ts = two_sided([p_ for p_ in prof if p_[0] == dom[0]])
+        alg_b = dom_ts["algorithmic_bytes_per_launch"]
         roof = {"bound": "mfma", "kernel": sym(dom[0]), "kernel_class": class_names[dom[0][1:3]],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes/launch",
+                # algorithmic bytes: every operand and the output once (the same formula as two_sided.hbm_floor_ms)
+                "algorithmic_bytes": alg_b, "traffic_ratio": round(traffic / alg_b, 3) if (traffic and alg_b) else None,
                 "traffic_source": (f"committed profile profiles/{os.path.basename(tfile)} (separate rocprofv3 --pmc FETCH_SIZE / "
                                    f"WRITE_SIZE passes of this command, gfx950 2x FETCH_SIZE correction, keyed by kernel symbol; "
                                    f"not measured in this run: counters cannot be read live)") if traffic else None,
                 "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
                 "two_sided": {"note": "per launch max(MACs/2.5 PFLOP/s, algorithmic bytes/8 TB/s) summed, over measured time; "
                                       "three_sided adds the L2->LDS operand intake of the best 512-thread tile at 70 GB/s per CU",
-                              "dominant_kernel": two_sided([p_ for p_ in prof if p_[0] == dom[0]]),
+                              "dominant_kernel": dom_ts,
                               "all_gemms": two_sided(prof)},
                 "avg_launch_gflop": round(dom[1][0] / dom[1][2] / 1e9, 3),
                 "gemm_classes": {class_names[kd[1:3]]: {"tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 2), "ms": round(v[1], 2),
@@ -464,8 +470,8 @@ def main():
         g2.capture(bilevel=True)
 
         def it2(i):
-            d, n = d2[i % 2], d2[(i + 1) % 2]
-            g2.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=(n["lat"], n["noise"], n["t"], n["ehs"]))
+            d = d2[i % 2]
+            g2.main(d["lat"], d["noise"], d["t"], d["ehs"])
             if (i + 1) % a.upper_freq == 0:
                 g2.upper(d["lat"], d["noise"], d["t"], d["ehs"], e2)
         for i in range(2):
@@ -498,7 +504,13 @@ def main():
                                       f"concept-suppression step every {a.upper_freq}th iteration, second AdamW)"
                                       + (" [TINY DEBUG TOPOLOGY - not the benchmark]" if a.tiny else ""),
                           "global_batch": B * world, "parallelism": f"dp{world}", "student_params": student.num_parameters(),
-                          "weights": "random-init"},
+                          "weights": "random-init",
+                          # what the ranks really talked over (the driver's SCALE record can be checked against it)
+                          "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
+                          "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
+                          "dp_mode": st.reducer.mode + ("/native-comm" if st.reducer.comm is not None else ""),
+                          "curve_note": "the shipped bilevel YAML runs B=16/GPU: the N=1 point of THAT curve is extras.b16 "
+                                        "(N>1: rerun with --batch 16); `value` is configs[1]'s B=8/GPU"},
                "roofline": roof, "cpu_baseline": cpu, "extras": extras}
         print(json.dumps(out), flush=True)
     if world > 1:

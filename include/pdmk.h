@@ -344,7 +344,22 @@ int pdmk_comm_unique_id(void* out128);
 int pdmk_comm_create(const void* id128, int rank, int world, pdmk_comm_t* out);
 int pdmk_comm_allreduce_sum_f32(pdmk_comm_t comm, float* buf, int64_t n, pdmk_stream stream);
 int pdmk_comm_world(pdmk_comm_t comm);
+int pdmk_comm_rank(pdmk_comm_t comm);
 int pdmk_comm_destroy(pdmk_comm_t comm);
+/* The same exchange as its two halves ("bucketed RCCL reduce-scatter + all-gather over the 7 direct xGMI
+ * links"): the bucket is buf[0 .. world * n_per_rank); after pdmk_comm_reduce_scatter_sum_f32 rank r holds the sum of its
+ * share buf[r * n_per_rank .. (r + 1) * n_per_rank) (the other shares are unspecified), pdmk_comm_allgather_f32 then
+ * completes every share on every rank.  Both in place and asynchronous on `stream`; together they equal
+ * pdmk_comm_allreduce_sum_f32(buf, world * n_per_rank).  The caller pads a bucket to a multiple of `world`. */
+int pdmk_comm_reduce_scatter_sum_f32(pdmk_comm_t comm, float* buf, int64_t n_per_rank, pdmk_stream stream);
+int pdmk_comm_allgather_f32(pdmk_comm_t comm, float* buf, int64_t n_per_rank, pdmk_stream stream);
+
+/* Library-owned side streams: a plain non-blocking hipStream per role (communication, frozen-teacher pass,
+ * streamed optimiser, dgrad-copy refresh), created once per process by the host and never destroyed while work may be
+ * queued on it.  The reference gets its side stream from DDP's reducer (trainer.py:117-129); here the roles are explicit
+ * and can never alias one hipStream (a pooled stream object may).  -(1000 + hipError) on failure. */
+int pdmk_stream_create(int high_priority, pdmk_stream* out);
+int pdmk_stream_destroy(pdmk_stream stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,16 @@ GLOBAL_B, ITERS, UPPER_AT = 4, 3, 2
 LR, UPPER_LR = 1e-4, 2e-4
 
 
+def DEV_INDEX():
+    """LOCAL_RANK when the box has a device for it, else 0 (all ranks share the one GPU)."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return local if local < torch.cuda.device_count() else 0
+
+
+def DEV():
+    return f"cuda:{DEV_INDEX()}"
+
+
 def global_batches():
     g = torch.Generator().manual_seed(97)
     out = []
@@ -44,16 +54,16 @@ def run(mode, world, rank, out=None):
     ocfg, cfg = OCfg.tiny(), UNetConfig.tiny()
     dense = oweights.init_dense_state_dict(ocfg, seed=0)
     av = oarch.random_arch_vector(ocfg, 0.55, seed=0, drop_depth=(1, 9))
-    student = UNet2DConditionModelPruned(cfg, av, "cuda:0", torch.float32, train=True, init=False)
+    student = UNet2DConditionModelPruned(cfg, av, DEV(), torch.float32, train=True, init=False)
     student.load_dense_or_pruned(dense)
-    teacher = UNet2DConditionModelPruned(cfg, None, "cuda:0", torch.float32, train=False, init=False)
+    teacher = UNet2DConditionModelPruned(cfg, None, DEV(), torch.float32, train=False, init=False)
     teacher.load_dense_or_pruned(dense)
     st = BilevelStepper(student, teacher, lr=LR, upper_lr=UPPER_LR, bilevel=True, bucket_mb=1)
     st.reducer.bucket = max(1024, student.store.total // 5)        # several buckets + a ragged head on the tiny arena
     assert st.world == world
     B = GLOBAL_B // world
     rows = slice(rank * B, (rank + 1) * B)
-    data = [{n: v[rows].cuda() for n, v in d.items()} for d in global_batches()]
+    data = [{n: v[rows].to(DEV()) for n, v in d.items()} for d in global_batches()]
     store = student.store
     init = store.master.clone()
     graphs = None
@@ -61,7 +71,7 @@ def run(mode, world, rank, out=None):
         graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True)
         graphs.force_segments = True            # world 1 takes the multi-graph replay path too
         graphs.capture(bilevel=True)
-        assert len(graphs.g_main) == 3 + int(graphs.prefetch)     # + the cut between the loss heads and the backward
+        assert len(graphs.g_main.bwd) == 3 and graphs.g_main.teacher is not None
         assert torch.equal(store.master, init)  # capture restored the training state
     # ---- gradient of the first main step, reduced over the ranks, no optimiser
     d = data[ITERS]
@@ -69,10 +79,8 @@ def run(mode, world, rank, out=None):
         st.main_step(d["lat"], d["noise"], d["t"], d["ehs"])
         scale = st._gscale
     else:
-        if graphs.prefetch:
-            graphs.prime(d["lat"], d["noise"], d["t"], d["ehs"])
         graphs._load(d["lat"], d["noise"], d["t"], d["ehs"])
-        graphs._replay_step(graphs.g_main, graphs.main_offs, None)
+        graphs._replay_step(graphs.g_main, None)
         scale = 1.0 / world
     torch.cuda.synchronize()
     grad = (store.grad * scale).cpu()
@@ -87,8 +95,7 @@ def run(mode, world, rank, out=None):
                 st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
                 st.optimizer_step(upper=True)
         else:
-            n = data[it + 1] if it + 1 < ITERS else None      # announce the next batch: its teacher forward runs beside this step
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"], nxt=None if n is None else (n["lat"], n["noise"], n["t"], n["ehs"]))
+            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
             if it == UPPER_AT:
                 graphs.upper(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
     torch.cuda.synchronize()
@@ -104,7 +111,9 @@ def main():
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
-    torch.cuda.set_device(0)
+    # one device per rank when the box has them (LOCAL_RANK -> set_device, as bench.py / Trainer do); on a one-GPU box both
+    # ranks share cuda:0 (RCCL refuses that, gloo does not)
+    torch.cuda.set_device(DEV_INDEX())
     dist.init_process_group("gloo", rank=rank, world_size=world)
     run(a.mode, world, rank, a.out)
     dist.barrier()

@@ -22,14 +22,15 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _spawn(mode, world, out):
+def _spawn(mode, world, out, dp_mode="allreduce"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # LOCAL_RANK = rank: dp_worker puts each rank on its own device when the box has one per rank (else all on cuda:0)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", PDMK_DP_MODE=dp_mode)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), "--mode", mode, "--out", out],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -44,13 +45,15 @@ def _spawn(mode, world, out):
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_two_ranks_equal_one_rank_with_twice_the_batch(dev, tmp_path, mode):
+@pytest.mark.parametrize("mode,dp_mode", [("eager", "allreduce"), ("graph", "allreduce"), ("graph", "rs_ag")])
+def test_two_ranks_equal_one_rank_with_twice_the_batch(dev, tmp_path, mode, dp_mode):
+    """dp_mode rs_ag: every bucket as reduce-scatter + all-gather of `world` shares instead of one
+    all-reduce - the same sums, so the same bounds."""
     sys.path.insert(0, HERE)
     import dp_worker
     ref = dp_worker.run(mode, 1, 0)
-    out = str(tmp_path / f"dp_{mode}.pt")
-    _spawn(mode, 2, out)
+    out = str(tmp_path / f"dp_{mode}_{dp_mode}.pt")
+    _spawn(mode, 2, out, dp_mode)
     got = torch.load(out)
     assert torch.equal(got["init"], ref["init"])
     # gradient mean over ranks == gradient of the whole batch

@@ -7,15 +7,15 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="allreduce"):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, mode)
     except Exception as e:      # report instead of leaving the parent waiting on the queue
         q.put((rank, False, repr(e)))
         raise
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pdm.training.bilevel import GradReducer
@@ -24,8 +24,11 @@ def _worker_body(rank, world, port, q):
         total = 1000
         master = torch.zeros(1000)
         grad = torch.arange(1000, dtype=torch.float32) * (rank + 1)
-    red = GradReducer(Store, bucket_mb=1)
-    red.bucket = 256                      # elements: forces several buckets + a ragged head
+    red = GradReducer(Store, bucket_mb=1, mode=mode)
+    red.bucket = 256 if mode == "allreduce" else 255     # elements: several buckets + a ragged head (rs_ag: 255 is odd, so
+    if mode == "rs_ag":                                  # every bucket has a share body AND a one-element tail all-reduce)
+        _rs_ag_body(red, Store, rank, world, q)
+        return
     red.begin()
     launched = []
     orig = red._launch
@@ -39,6 +42,38 @@ def _worker_body(rank, world, port, q):
     expect = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world))
     q.put((rank, bool(torch.equal(Store.grad, expect)), scale))
     dist.destroy_process_group()
+
+
+def _rs_ag_body(red, Store, rank, world, q):
+    red.begin()
+    launched = []
+    orig = red._launch
+    red._launch = lambda lo, hi: (launched.append((lo, hi)), orig(lo, hi))[1]
+    red.ready_down_to(700)
+    assert launched == [(745, 1000)], launched
+    assert red.n_collectives == 3, red.n_collectives      # reduce-scatter + all-gather of 254 elements, all-reduce of 1
+    red.ready_down_to(0)
+    assert launched == [(745, 1000), (490, 745), (235, 490)], launched
+    scale = red.finish()                                  # the head [0, 235): 234 in shares + 1
+    assert launched[-1] == (0, 235) and scale == 1.0 / world
+    expect = torch.arange(1000, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    q.put((rank, bool(torch.equal(Store.grad, expect)), scale))
+    dist.destroy_process_group()
+
+
+def test_bucketed_reduce_scatter_allgather_world2_gloo():
+    """PDMK_DP_MODE=rs_ag: every bucket as reduce-scatter + all-gather of `world` equal shares plus an all-reduce of the
+    (n mod world) tail - the bucket / share arithmetic of SURVEY 5 / 8e, over gloo (share-wise reduce + broadcast, the same
+    data movement; over RCCL: ncclReduceScatter / ncclAllGather in place)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30512 + os.getpid() % 1000
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q, "rs_ag")) for r in range(2)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(60) for p in ps]
+    assert all(ok for _, ok, _ in res), res
+    assert all(p.exitcode == 0 for p in ps)
 
 
 def test_bucketed_allreduce_world2_gloo():

@@ -235,13 +235,13 @@ def test_segmented_graph_replay_matches_eager(dev):
     ref = student.store.grad.clone()
     ref_loss = st.losses.clone()
     for nseg in (1, 4):
-        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False, prefetch=False)
+        g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False)
         g.force_segments = nseg > 1
         g.capture(bilevel=False)
-        assert len(g.g_main) == nseg, (len(g.g_main), g.main_offs)
+        assert len(g.g_main.bwd) == nseg and g.g_main.teacher is not None, (len(g.g_main.bwd), g.g_main.offs)
         student.store.grad.zero_()
         g._load(lat, noise, t, ehs)
-        g._replay_step(g.g_main, g.main_offs)
+        g._replay_step(g.g_main)
         torch.cuda.synchronize()
         assert torch.allclose(st.losses, ref_loss, rtol=5e-3, atol=1e-6)       # split-K atomics: not bit-reproducible
         rel = (student.store.grad - ref).abs().max().item() / ref.abs().max().item()
@@ -285,13 +285,13 @@ def test_streamed_adamw_matches_step_then_optimizer(dev, forced):
         assert d.mean().item() <= 2e-3 * a.abs().mean().item() + 1e-6, (what, d.mean().item(), a.abs().mean().item())
 
 
-def test_teacher_prefetch_matches_in_step_teacher(dev):
-    """GraphedBilevel runs the frozen teacher's forward of batch i+1 as its own graph beside the student's step on batch i
-    and hands its outputs over through static buffers.  Four iterations on four different batches (with one upper step in
-    between, which must not disturb the hand-over) give the same losses and parameters as computing the teacher inside
-    every step - with the next batch announced (`nxt`), and without (every call primes).  Teacher GROUPING (one dense
-    teacher forward over this batch and the next k-1 announced ones, each step taking its slice) gives the same too, for
-    k = 2 and 3 and when nothing is announced (the group is padded with the current batch)."""
+def test_graph_replay_with_teacher_graph_matches_eager_and_survives_recapture(dev):
+    """The graph mode of round 3: every captured graph is single-stream (teacher, student forward, loss heads + backward
+    segments), the teacher graph replays on the teacher stream beside the student forward, the AdamW of every finished
+    share on the opt stream.  Four bilevel iterations on four different batches (one upper step in between) must give the
+    eager mode's losses and parameters.  Then the sequence a training job with a ragged last batch walks - capture B = 2,
+    replay, capture B = 1, replay, replay B = 2 again, close B = 1, capture a THIRD executor set, replay - all in this one
+    process: the pattern that crashed hipGraphLaunch (hip::Graph::UpdateStreams) while graphs had parallel branches."""
     from pdm.training.bilevel import BilevelStepper, GraphedBilevel
     g = torch.Generator().manual_seed(5)
     batches = [tuple(x.cuda() for x in (torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g),
@@ -299,30 +299,50 @@ def test_teacher_prefetch_matches_in_step_teacher(dev):
                for _ in range(4)]
     empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous().cuda()
     results = []
-    for mode in ("in_step", "prefetch", "prime_only", "group2", "group3", "group2_unannounced"):
+    for mode in ("eager", "graph"):
         ocfg, dense, psd, info, student, teacher = _setup(torch.float32)
         st = BilevelStepper(student, teacher, lr=1e-4, upper_lr=1e-4, bilevel=True)
-        grp = int(mode[5]) if mode.startswith("group") else 1
-        gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3, prefetch=mode in ("prefetch", "prime_only"), teacher_group=grp)
-        assert gr.prefetch == (mode in ("prefetch", "prime_only")) and gr.tgroup == grp
-        gr.capture(bilevel=True)
-        assert len(gr.g_main) == (2 if gr.prefetch else 1)
+        if mode == "graph":
+            gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3)
+            gr.capture(bilevel=True)
+            assert gr.g_main.teacher is not None and gr.g_upper.teacher is not None and len(gr.g_main.bwd) >= 2
         losses = []
         for i, b in enumerate(batches):
-            if mode in ("group2", "group3"):       # one dense teacher forward over this and the next grp-1 announced batches
-                nxt = [batches[(i + j) % 4] for j in range(1, grp)]
+            if mode == "graph":
+                gr.main(*b)
             else:
-                nxt = batches[(i + 1) % 4] if mode == "prefetch" else None
-            gr.main(*b, nxt=nxt)
+                st.main_step(*b)
+                st.optimizer_step()
             losses.append(st.losses.clone())
             if i == 1:
-                gr.upper(*b, empty)
+                if mode == "graph":
+                    gr.upper(*b, empty)
+                else:
+                    st.upper_step(*b, empty)
+                    st.optimizer_step(upper=True)
         torch.cuda.synchronize()
         results.append((torch.stack(losses).cpu(), student.store.master.clone()))
-    for other in results[1:]:
-        assert torch.allclose(other[0], results[0][0], rtol=1e-5, atol=1e-9), (other[0], results[0][0])
-        d, dr = (other[1] - results[0][1]).abs().max().item(), results[0][1].abs().max().item()
-        assert d <= 1e-5 * dr + 8e-4, d          # Adam turns round-off-sized gradients into +-lr steps (see the DP test)
+    assert torch.allclose(results[1][0], results[0][0], rtol=1e-5, atol=1e-9), (results[1][0], results[0][0])
+    d, dr = (results[1][1] - results[0][1]).abs().max().item(), results[0][1].abs().max().item()
+    assert d <= 1e-5 * dr + 8e-4, d          # Adam turns round-off-sized gradients into +-lr steps (see the DP test)
+    # ---- shape change -> second executor set -> back -> eviction -> third set, in this process
+    one = tuple(x[:1].contiguous() for x in batches[0])
+    g1 = GraphedBilevel(st, 1, 4, 16, 16, 13, 64, segments=3)
+    g1.capture(bilevel=True)
+    g1.main(*one)
+    g1.upper(*one, empty[:1].contiguous())
+    gr.main(*batches[1])
+    g1.main(*one)
+    g1.close()
+    g3 = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=2)
+    g3.capture(bilevel=True)
+    g3.main(*batches[2])
+    gr.main(*batches[3])
+    g3.upper(*batches[2], empty)
+    torch.cuda.synchronize()
+    assert torch.isfinite(st.losses).all() and torch.isfinite(student.store.master).all()
+    for x in (gr, g3):
+        x.close()
 
 
 @pytest.mark.parametrize("dn,tol", [("f32", 1e-3), ("bf16", 2e-2)])

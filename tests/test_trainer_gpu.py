@@ -114,7 +114,13 @@ def test_epochs_validation_and_input_perturbation(dev, tmp_path):
         UnetFineTuner(c2)
 
 
-def _hip_graph_mode_body(tmp_path):
+def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
+    """`training.hip_graphs`: Trainer.train() replays the captured step (what bench.py measures) instead of eager launches;
+    same seeded batches -> the same loss curve and the same final weights as the eager trainer (bf16 engine; split-K
+    atomics order is the only difference), same cadence and log keys.
+    In-process again (round 2 ran it in a child process): every captured graph is now single-stream, so hipGraphLaunch never
+    enters hip::Graph::UpdateStreams, whose out-of-bounds read of the executor's parallel-stream list was the segfault
+    (DESIGN.md 2)."""
     from pdm.training.trainer import BilevelUnetFineTuner
     runs = []
     for mode in (False, True):
@@ -124,6 +130,8 @@ def _hip_graph_mode_body(tmp_path):
         tr.train()
         recs = [json.loads(l) for l in open(tmp_path / ("g" if mode else "e") / "metrics.jsonl")]
         runs.append((recs, tr.prediction_model.store.master.clone(), tr.stepper.opt.t, tr.stepper.upper_opt.t))
+        if mode:
+            assert len(tr._graphs) == 1
     (re, we, te, ue), (rg, wg, tg, ug) = runs
     assert (te, ue) == (tg, ug) == (6, 2) and len(re) == len(rg) == 6
     assert [sorted(r) for r in re] == [sorted(r) for r in rg]
@@ -134,23 +142,42 @@ def _hip_graph_mode_body(tmp_path):
     assert d.max().item() <= 5e-3 and d.mean().item() <= 2e-3 * we.abs().mean().item() + 1e-6, (d.max().item(), d.mean().item())
 
 
-def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
-    """`training.hip_graphs`: Trainer.train() replays the captured step (what bench.py measures) instead of eager launches;
-    same seeded batches -> the same loss curve and the same final weights as the eager trainer (bf16 engine; split-K
-    atomics order is the only difference), same cadence and log keys.
-    Runs in a process of its own, like a training job does: in a pytest process that has already built and destroyed the
-    multi-stream graphs of tests/test_step_parity_gpu.py, ROCm 7.2's hipGraphLaunch segfaults on the first replay of a newly
-    captured graph (rocgdb: hip::Graph::UpdateStreams <- hip::GraphExec::Run <- hipGraphLaunch; reproducible with
-    `pytest tests/test_step_parity_gpu.py tests/test_trainer_gpu.py`, not with any single test of that file in front, not
-    in a fresh process) - a runtime state this library has no handle on; DESIGN.md 2."""
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys, pathlib; sys.path.insert(0, %r); import conftest, test_trainer_gpu; "
-            "test_trainer_gpu._hip_graph_mode_body(pathlib.Path(%r))" % (here, str(tmp_path)))
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
-                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert p.returncode == 0, p.stdout[-4000:]
+def test_hip_graph_mode_keeps_one_capture_per_batch_shape(dev, tmp_path):
+    """A dataloader whose last batch of every epoch is ragged (3 batches of B = 2, 2, 1; two epochs): graph mode captures each
+    batch shape ONCE and keeps it (round 2 dropped and re-captured the executors at every shape change, the sequence that
+    crashed hipGraphLaunch); the cache holds `training.hip_graph_shapes` shapes and closes the least recently used one at
+    an idle point; clip_grad_norm with hip_graphs is rejected when the trainer is built, not at the first step."""
+    from pdm.training import bilevel
+    from pdm.training.trainer import BilevelUnetFineTuner, SyntheticBatches
+    cfg = _config(tmp_path, 6)
+    cfg["training"]["hip_graphs"] = True
+    cfg["training"]["hip_graph_shapes"] = 2
+    full = list(b for _, b in zip(range(2), SyntheticBatches(2, 16, 13, 64, 7, "cuda")))
+    tail = {k_: v[:1].contiguous() for k_, v in full[0].items()}
+    captures = []
+    orig = bilevel.GraphedBilevel.capture
+    bilevel.GraphedBilevel.capture = lambda self, bilevel=True: (captures.append(self.shape), orig(self, bilevel))[1]
+    try:
+        tr = BilevelUnetFineTuner(cfg, train_dataloader=full + [tail], upper_dataloader=[full[0]])
+        tr.train()
+        assert tr.global_step == 6 and tr.stepper.opt.t == 6
+        assert sorted(s_[0] for s_ in captures) == [1, 2], captures            # one capture per shape over two epochs
+        assert len(tr._graphs) == 2
+        # a third shape evicts the least recently used one (closed, not just dropped)
+        first = next(iter(tr._graphs.values()))
+        three = {k_: torch.cat([v, v[:1]]) for k_, v in full[0].items()}
+        tr.step(three)
+        assert len(tr._graphs) == 2 and first.closed and len(captures) == 3
+        torch.cuda.synchronize()
+        assert torch.isfinite(tr.prediction_model.store.master).all()
+    finally:
+        bilevel.GraphedBilevel.capture = orig
+    c2 = _config(tmp_path / "clip", 1)
+    c2["training"]["hip_graphs"] = True
+    c2["training"]["optim"]["clip_grad_norm"] = True
+    c2["training"]["optim"]["max_grad_norm"] = 1.0
+    with pytest.raises(ValueError):
+        BilevelUnetFineTuner(c2)
 
 
 def test_pixel_batches_go_through_the_vae(dev, tmp_path):

@@ -628,6 +628,11 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
             }
         }
     }
+    // the last events of the paired / steady paths issue weight-tile and patch DMAs that nobody waits for (all out of range:
+    // zeros into LDS); the epilogue reuses that LDS as its staging image, so drain them explicitly - a late zero write
+    // must not land on a staged tile, and what __syncthreads() happens to emit is not a contract
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
     else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true>(g, acc, smem, mbase, n0, tw, W);
 }

@@ -103,6 +103,11 @@ _SIGS = {
     "pdmk_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
     "pdmk_comm_allreduce_sum_f32": ([vp, vp, i64, vp], i32),
     "pdmk_comm_world": ([vp], i32),
+    "pdmk_comm_rank": ([vp], i32),
+    "pdmk_comm_reduce_scatter_sum_f32": ([vp, vp, i64, vp], i32),
+    "pdmk_comm_allgather_f32": ([vp, vp, i64, vp], i32),
+    "pdmk_stream_create": ([i32, C.POINTER(vp)], i32),
+    "pdmk_stream_destroy": ([vp], i32),
     "pdmk_comm_destroy": ([vp], i32),
 }
 for _n, (_a, _r) in _SIGS.items():
@@ -214,10 +219,40 @@ class Comm:
         assert t.dtype == torch.float32 and t.is_contiguous()
         _chk(_lib.pdmk_comm_allreduce_sum_f32(self._h, _p(t), t.numel(), _st()), "pdmk_comm_allreduce_sum_f32")
 
+    def reduce_scatter_sum_(self, t):
+        """t: contiguous fp32 bucket of world * n elements; afterwards this rank's share t[rank*n:(rank+1)*n] holds the sum."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % self.world == 0
+        _chk(_lib.pdmk_comm_reduce_scatter_sum_f32(self._h, _p(t), t.numel() // self.world, _st()),
+             "pdmk_comm_reduce_scatter_sum_f32")
+
+    def all_gather_(self, t):
+        """Completes every rank's share of the bucket on every rank (second half of the all-reduce)."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % self.world == 0
+        _chk(_lib.pdmk_comm_allgather_f32(self._h, _p(t), t.numel() // self.world, _st()), "pdmk_comm_allgather_f32")
+
     def close(self):
         if self._h is not None:
             _lib.pdmk_comm_destroy(self._h)
             self._h = None
+
+
+_ROLE_STREAMS = {}
+
+
+def role_stream(device, role, high_priority=False):
+    """The process-wide dedicated HIP stream of a role ("teacher", "opt", "wt", "comm", "capture", ...) on `device`:
+    created once through pdmk_stream_create and wrapped for torch - never one of torch's 32 pooled streams, which are handed
+    out round-robin and start to alias after a few stepper / graph instances.  Never destroyed (work may be queued on it)."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), role)
+    s = _ROLE_STREAMS.get(key)
+    if s is None:
+        h = vp()
+        with torch.cuda.device(key[0]):
+            _chk(_lib.pdmk_stream_create(int(high_priority), C.byref(h)), "pdmk_stream_create")
+        s = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", key[0]))
+        _ROLE_STREAMS[key] = s
+    return s
 
 
 def groupnorm_ws(device, B, G, have=None):

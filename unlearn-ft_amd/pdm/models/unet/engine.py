@@ -67,8 +67,10 @@ class UNetEngine:
         # skip k (push order) is concatenated behind an h of cat_ch[k] channels (None: its consumer ResBlock is dropped)
         ups = [r for b in blocks if b.kind == "up" for r in b.resnets]
         self.cat_ch = [None if r.dropped else padc(r.cin - r.skip) for r in reversed(ups)]
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev)
-        self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"   # pays only when launch-bound (eager)
+        # (eager mode only, opt-in, measured slower once the ring kernels own the LDS: PDMK_WGRAD_ASYNC=1; never under
+        # stream capture - captured graphs are single-stream, bilevel.py GraphedBilevel)
+        self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
+        self.wgrad_stream = k.role_stream(self.dev, "wgrad") if self.wgrad_async else None
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -113,7 +115,7 @@ class UNetEngine:
     def _wgrad(self, fn, *operands):
         """Launch a weight-gradient kernel.  Side stream: it starts once everything queued on the main stream so far
         (in particular dy) is done; its operands stay referenced until the next join."""
-        if not self.wgrad_async:
+        if not self.wgrad_async or torch.cuda.is_current_stream_capturing():
             fn()
             return
         main = torch.cuda.current_stream()

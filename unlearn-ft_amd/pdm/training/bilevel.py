@@ -10,7 +10,6 @@ Reference arithmetic:
 """
 import gc
 import math
-
 import os
 
 import torch
@@ -39,6 +38,9 @@ class FusedAdamW:
         self._sched_dev = torch.tensor([0.0, 1.0, 1.0], device=dev)    # bc = 1, not 0: a launch() before the first prepare()
         self.lr_dev, self.bc_dev = self._sched_dev[:1], self._sched_dev[1:]      # (graph warm-up) must not divide by 0
         self._sched_host = torch.zeros(32, 3).pin_memory() if dev.type == "cuda" else torch.zeros(32, 3)
+        # one event per ring row, recorded behind that row's copy: a row is rewritten only after its copy has executed (a
+        # host that replays graphs can run more than 32 steps ahead of the device; in the steady state the wait is free)
+        self._sched_ev = [None] * self._sched_host.shape[0]
         self.t = 0                     # optimiser steps taken
         self.sched_k = 0               # scheduler.step() calls (accelerate steps it `sched_mult`=W times per opt step)
         self.warmup = warmup_steps     # already multiplied by W by the caller (trainer.py:436-443)
@@ -53,9 +55,16 @@ class FusedAdamW:
         """Host-side part of a step (never captured in a graph): advance t, publish lr and bias corrections."""
         self.t += 1
         lr = self.current_lr()
-        row = self._sched_host[self.t % self._sched_host.shape[0]]      # 32 steps of run-ahead before a row is reused
+        slot = self.t % self._sched_host.shape[0]
+        row = self._sched_host[slot]
+        if self._sched_ev[slot] is not None:
+            self._sched_ev[slot].synchronize()      # the copy that last read this pinned row has executed
         row[0], row[1], row[2] = lr, 1 - self.betas[0] ** self.t, 1 - self.betas[1] ** self.t
         self._sched_dev.copy_(row, non_blocking=True)
+        if self._sched_dev.is_cuda:
+            if self._sched_ev[slot] is None:
+                self._sched_ev[slot] = torch.cuda.Event()
+            self._sched_ev[slot].record()
         self.sched_k += self.sched_mult
         return lr
 
@@ -131,20 +140,29 @@ class GradReducer:
     """Data-parallel mean of the flat gradient arena over RCCL (`nccl` backend) / gloo.
 
     Reference = DDP's bucketed all-reduce inside accelerator.backward (trainer.py:2782, 2808).  Here the arena is
-    reduced in `bucket_mb` slices issued on a side stream as soon as the backward pass has produced them (the arena is
-    laid out in forward order, so the tail is final first); the division by world size is folded into AdamW."""
+    reduced in `bucket_mb` slices issued on the dedicated comm stream as soon as the backward pass has produced them (the
+    arena is laid out in forward order, so the tail is final first); the division by world size is folded into AdamW.
 
-    def __init__(self, store, bucket_mb=64):
+    mode "allreduce" (default): one all-reduce per bucket.  mode "rs_ag" (PDMK_DP_MODE=rs_ag): every bucket
+    as reduce-scatter + all-gather of world equal shares - over RCCL each rank receives its share directly from its xGMI
+    peers; a bucket's last (n mod world) elements ride in a small all-reduce.  Both modes give the same sums.
+    transport: torch.distributed's process group (default) or the library's own communicator (PDMK_COMM=native)."""
+
+    def __init__(self, store, bucket_mb=64, mode=None):
         self.store = store
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
         self.bucket = bucket_mb * (1 << 20) // 4
-        self.stream = torch.cuda.Stream() if (self.world > 1 and store.master.is_cuda) else None
-        self.handles = []
+        self.mode = mode or os.environ.get("PDMK_DP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"PDMK_DP_MODE={self.mode!r}: expected 'allreduce' or 'rs_ag'")
+        self.stream = k.role_stream(store.master.device, "comm") if (self.world > 1 and store.master.is_cuda) else None
         self.next_hi = store.total
         self.flush_cb = None               # set by the stepper: the engine's flush_pending()
-        # PDMK_COMM=native: the all-reduces go through the library's own communicator handle (pdmk_comm_t, RCCL bound inside
+        self.n_collectives = 0             # collectives issued since begin() (tests / bench bookkeeping)
+        self.backend = dist.get_backend() if self.world > 1 else "none"
+        # PDMK_COMM=native: the collectives go through the library's own communicator handle (pdmk_comm_t, RCCL bound inside
         # libpdmk.so) instead of torch.distributed's process group; the 128-byte id travels over torch.distributed once.
-        # Default: torch.distributed (backend "nccl" = RCCL) - the path the gloo rehearsal tests cover.
         self.comm = None
         if self.world > 1 and store.master.is_cuda and os.environ.get("PDMK_COMM") == "native":
             box = [k.Comm.unique_id() if dist.get_rank() == 0 else None]
@@ -153,7 +171,7 @@ class GradReducer:
 
     def begin(self):
         self.next_hi = self.store.total
-        self.handles = []
+        self.n_collectives = 0
 
     def ready_down_to(self, lo):
         """Everything in [lo, total) is final: launch whole buckets from the tail (called from the backward tape)."""
@@ -166,9 +184,40 @@ class GradReducer:
             self._launch(self.next_hi - self.bucket, self.next_hi)
             self.next_hi -= self.bucket
 
+    # ---- one bucket
+    def _all_reduce(self, t):
+        self.n_collectives += 1
+        if self.comm is not None:
+            self.comm.all_reduce_sum_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def _rs_ag(self, t):
+        """Sum of bucket `t` over the ranks as reduce-scatter + all-gather of `world` equal shares (+ a tail all-reduce)."""
+        W = self.world
+        n = t.numel() - t.numel() % W
+        if n:
+            body = t[:n]
+            per = n // W
+            mine = body[self.rank * per:(self.rank + 1) * per]
+            self.n_collectives += 2
+            if self.comm is not None:
+                self.comm.reduce_scatter_sum_(body)
+                self.comm.all_gather_(body)
+            elif self.backend == "gloo":        # gloo has no reduce-scatter: the same data movement share by share
+                for r in range(W):
+                    dist.reduce(body[r * per:(r + 1) * per], dst=r, op=dist.ReduceOp.SUM)
+                for r in range(W):
+                    dist.broadcast(body[r * per:(r + 1) * per], src=r)
+            else:
+                dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(body, mine)
+        if n < t.numel():
+            self._all_reduce(t[n:])
+
     def _launch(self, lo, hi):
         g = self.store.grad[lo:hi]
-        reduce_ = self.comm.all_reduce_sum_ if self.comm is not None else (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        reduce_ = self._rs_ag if self.mode == "rs_ag" else self._all_reduce
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream), phase("allreduce"):
@@ -181,6 +230,8 @@ class GradReducer:
         if self.world == 1:
             return 1.0
         if self.next_hi > 0:
+            if self.flush_cb is not None:
+                self.flush_cb()
             self._launch(0, self.next_hi)
             self.next_hi = 0
         if self.stream is not None:
@@ -188,7 +239,17 @@ class GradReducer:
         return 1.0 / self.world
 
 
+class _StepCtx:
+    """What the pieces of one step hand to each other (forward inputs / outputs of the student)."""
+    __slots__ = ("B", "C", "H", "W", "timesteps", "noisy", "target", "ehs", "pred", "acts")
+
+
 class BilevelStepper:
+    """The step as capturable pieces.  Eager mode (`main_step` / `upper_step`) composes them over the dedicated role
+    streams (teacher pass and dgrad-copy refresh beside the student forward); graph mode (GraphedBilevel) captures every
+    piece as a SINGLE-STREAM hipGraph and does the same composition between the graphs - no piece switches streams when
+    `in_graph` is set."""
+
     def __init__(self, student, teacher, *, w_diff=1.0, w_dist=2.0, w_block=0.1, snr_gamma=5.0, up_w_diff=0.0,
                  up_w_dist=1.0, up_w_block=0.0, prediction_type="v_prediction", lr=1e-6, upper_lr=5e-6,
                  betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, warmup_steps=0, upper_warmup_steps=0,
@@ -213,18 +274,19 @@ class BilevelStepper:
         self.reducer.flush_cb = student.engine.flush_pending
         self.defer_reduce = False
         self.segment_cb = None
-        self.after_loss_cb = None      # GraphedBilevel: cut the captured graph between the loss heads and the backward
+        self.in_graph = False          # GraphedBilevel: the pieces run under stream capture, on ONE stream
         self._gscale = 1.0 / world
-        # the frozen teacher pass and the student forward are independent until the loss heads: they run on two HIP
-        # streams (two parallel branches once captured in a hipGraph) so the small-grid layers of one fill the CUs the
-        # other leaves idle
-        # teacher forward on its own stream (independent of the student forward); PDMK_TEACHER_STREAM=0 runs it in line
-        self.teacher_stream = (torch.cuda.Stream(device=self.dev) if os.environ.get("PDMK_TEACHER_STREAM", "1") != "0"
-                               else None)
-        self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # 32 bytes: zeroed by k.zero_   # diff, dist, block, (unused)
+        # the frozen teacher pass and the student forward are independent until the loss heads: two HIP streams, so that the
+        # small-grid layers of one fill the CUs the other leaves idle (PDMK_TEACHER_STREAM=0 runs the teacher in line).
+        # Every role has ONE dedicated stream per process (k.role_stream): never a pooled torch stream, which would alias
+        # another role after a few stepper instances.
+        cuda = self.dev.type == "cuda"
+        self.teacher_stream = (k.role_stream(self.dev, "teacher")
+                               if cuda and os.environ.get("PDMK_TEACHER_STREAM", "1") != "0" else None)
+        self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused); zeroed by k.zero_
         # transposed (dgrad) weight copies are refreshed at the START of the next training step, beside its forward, instead
         # of at the end of the optimiser step (PDMK_DEFER_WT=0: refresh with the optimiser as before)
-        self.wt_stream = torch.cuda.Stream(device=self.dev)
+        self.wt_stream = k.role_stream(self.dev, "wt") if cuda else None
         self._wt_pending = False
         student.store.defer_wt = os.environ.get("PDMK_DEFER_WT", "1") != "0"
 
@@ -244,7 +306,9 @@ class BilevelStepper:
         return e.to(self.dev).to(self.student.dtype).reshape(e.shape[0] * e.shape[1], e.shape[2]).contiguous()
 
     def _block_loss(self, acts_s, acts_t, B, weight, t_row0=0, seed=True):
-        """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds."""
+        """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds; t_row0: first teacher row
+        (the upper step reads the UNCONDITIONAL half of the 2B teacher batch: the reference's teacher hooks hold the last
+        teacher call, trainer.py:2951-2954)."""
         # when every layer of a block is dropped and it has no sampler, two hook keys hold the SAME activation (e.g. both
         # resnets of down_blocks.3 dropped: acts['d3'] is acts['d2']): its gradient seed is the sum of both terms
         seeded = set()
@@ -260,22 +324,27 @@ class BilevelStepper:
             k.mse_fwd_bwd(a.t, bt, None, self.losses, 2, a.g if (seed and weight > 0) else None, B, M // B, C,
                           a.t.stride(0), bt.stride(0), C, 1.0 / n, 2.0 * weight / n, again)
 
-    def _begin_wt_refresh(self):
+    def begin_wt_refresh(self):
         """The dgrad copies `wt` (W^T, flipped conv taps) of the weights the last optimiser step wrote are only read by the
-        backward pass: their refresh (one 3.4 GB HBM-bound pass) runs on a side stream beside the forward."""
+        backward pass: their refresh (one 3.4 GB HBM-bound pass) runs on the wt stream beside the forward.  Never captured:
+        GraphedBilevel calls it between its graphs."""
         store = self.student.store
-        if not store.defer_wt:
+        if not store.defer_wt or self.wt_stream is None:
             return
-        cur = torch.cuda.current_stream()
-        self.wt_stream.wait_stream(cur)
+        self.wt_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.wt_stream), phase("wt_refresh"):
             store.refresh_wt()
         self._wt_pending = True
 
-    def _backward_and_reduce(self):
+    def join_wt_refresh(self):
         if self._wt_pending:
             torch.cuda.current_stream().wait_stream(self.wt_stream)
             self._wt_pending = False
+
+    def backward(self):
+        """Backward pass of the student + gradient reduction; returns the gradient scale for AdamW (1 / world)."""
+        if not self.in_graph:
+            self.join_wt_refresh()
         if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between captured graphs
             self.student.engine.grad_ready_cb = self.segment_cb      # None, or GraphedBilevel's capture-segment switch
             self.student.engine.backward()
@@ -289,87 +358,64 @@ class BilevelStepper:
         self.reducer.begin()
         return self.reducer.finish()
 
-    # ------------------------------------------------------------------ steps
     def teacher_pass(self, latents, noise, timesteps, prompt_embeds, input_noise=None):
         """The frozen teacher's part of a main step on its own: forward diffusion + dense forward (trainer.py:2446-2448).
-        Returns (pred Act, {block key: Act}).  The teacher does not depend on the student, so GraphedBilevel runs this for
-        batch i+1 beside the student's backward pass of batch i and hands the result to main_step(teacher_out=...)."""
+        Returns (pred Act, {block key: Act}).  It reads nothing the student writes."""
         B, C, H, W = latents.shape
         with phase("fwd_teacher"):
             noisy, _ = self._diffuse(latents, noise if input_noise is None else input_noise, timesteps, False)
             return self.teacher.forward_nhwc(noisy, timesteps, self._ehs2d(prompt_embeds), B, H, W, train=False)
 
-    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True, input_noise=None, teacher_out=None):
-        """latents/noise [B,4,H,W] fp32 (latents already x scaling_factor), timesteps int64 [B], prompt_embeds [B,T,ctx].
-        input_noise: the perturbed noise of `input_perturbation` (trainer.py:2416-2417, 2427-2428) - it enters the forward
-        process, while the target is formed from the clean `noise`.
-        teacher_out: (pred, acts) of `teacher_pass` on the same inputs, computed earlier (the teacher is then not run here).
-        Returns the device tensor [diff, dist, block, 0] (float64); total = w_diff*diff + w_block*block + w_dist*dist."""
+    def upper_teacher_pass(self, latents, noise, timesteps, prompt_embeds, empty_prompt_embeds):
+        """Teacher cond + uncond predictions of the upper step as ONE batch of 2B (trainer.py:2951-2954)."""
         B, C, H, W = latents.shape
-        w = self.w
-        need_teacher = w["block"] > 0 or w["dist"] > 0
-        if backward:
-            self._begin_wt_refresh()
+        with phase("fwd_teacher"):
+            noisy, _ = self._diffuse(latents, noise, timesteps, False)
+            ehs2 = torch.cat([self._ehs2d(prompt_embeds), self._ehs2d(empty_prompt_embeds)], 0)
+            noisy2 = torch.cat([noisy, noisy], 0)
+            t2 = torch.cat([timesteps, timesteps], 0)
+            return self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
+
+    def student_forward(self, latents, noise, timesteps, prompt_embeds, train=True, input_noise=None, want_target=True):
+        """Forward diffusion (trainer.py:2409-2445) + student forward; zeroes the loss accumulators."""
+        ctx = _StepCtx()
+        ctx.B, ctx.C, ctx.H, ctx.W = latents.shape
+        ctx.timesteps = timesteps
         with phase("diffuse"):
-            noisy, target = self._diffuse(latents, noise, timesteps, True)
+            ctx.noisy, ctx.target = self._diffuse(latents, noise, timesteps, want_target)
             if input_noise is not None:
-                noisy, _ = self._diffuse(latents, input_noise, timesteps, False)
-            ehs = self._ehs2d(prompt_embeds)
+                ctx.noisy, _ = self._diffuse(latents, input_noise, timesteps, False)
+            ctx.ehs = self._ehs2d(prompt_embeds)
             k.zero_(self.losses)
-        cur = torch.cuda.current_stream()
-        ts = self.teacher_stream if self.teacher_stream is not None else cur
-        if teacher_out is not None:
-            pred_t, acts_t = teacher_out
-        elif need_teacher:
-            ts.wait_stream(cur)
-            with torch.cuda.stream(ts), phase("fwd_teacher"):
-                pred_t, acts_t = self.teacher.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=False)
         with phase("fwd_student"):
-            pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
-        if need_teacher and teacher_out is None:
-            cur.wait_stream(ts)
+            ctx.pred, ctx.acts = self.student.forward_nhwc(ctx.noisy, timesteps, ctx.ehs, ctx.B, ctx.H, ctx.W, train=train)
+        self.last_pred = ctx.pred
+        return ctx
+
+    def main_loss_heads(self, ctx, teacher_out, backward=True):
+        """DDPM min-SNR head + output distillation + block-feature distillation (trainer.py:2451-2488) and their seeds."""
+        w = self.w
+        B, C, H, W = ctx.B, ctx.C, ctx.H, ctx.W
+        pred, target = ctx.pred, ctx.target
         with phase("loss"):
-            wb = self.snr_w[timesteps].contiguous()
+            wb = self.snr_w[ctx.timesteps].contiguous()
             HW, cp, n = H * W, pred.t.shape[1], B * H * W * C
             k.mse_fwd(pred.t, target, wb, self.losses, 0, B, HW, C, cp, cp, 1.0 / n)
             if w["dist"] > 0:
-                k.mse_fwd(pred.t, pred_t.t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
+                k.mse_fwd(pred.t, teacher_out[0].t, None, self.losses, 1, B, HW, C, cp, cp, 1.0 / n)
             if backward:
                 pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
                 k.mse_bwd(pred.t, target, wb, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["diff"] / n, False)
                 if w["dist"] > 0:
-                    k.mse_bwd(pred.t, pred_t.t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
+                    k.mse_bwd(pred.t, teacher_out[0].t, None, pred.g, B, HW, C, cp, cp, cp, 2.0 * w["dist"] / n, True)
             if w["block"] > 0:
-                self._block_loss(acts, acts_t, B, w["block"], seed=backward)
-        self.last_pred = pred
-        if self.after_loss_cb is not None:
-            self.after_loss_cb()
-        if backward:
-            with phase("bwd"):
-                self._gscale = self._backward_and_reduce()
-        return self.losses
+                self._block_loss(ctx.acts, teacher_out[1], B, w["block"], seed=backward)
 
-    def upper_step(self, latents, noise, timesteps, prompt_embeds, empty_prompt_embeds, backward=True):
-        """Concept-suppression objective: w * mse(student(x_t, c), e_u - (e_c - e_u)) with the teacher's cond / uncond
-        predictions computed as ONE batch of 2B."""
-        B, C, H, W = latents.shape
+    def upper_loss_heads(self, ctx, teacher_out, backward=True):
+        """mse(student(x_t, c), e_u - (e_c - e_u)) (trainer.py:2983-3001) and its seed."""
         w = self.w
-        if backward:
-            self._begin_wt_refresh()
-        noisy, _ = self._diffuse(latents, noise, timesteps, False)
-        ehs = self._ehs2d(prompt_embeds)
-        ehs2 = torch.cat([ehs, self._ehs2d(empty_prompt_embeds)], 0)
-        noisy2 = torch.cat([noisy, noisy], 0)
-        t2 = torch.cat([timesteps, timesteps], 0)
-        k.zero_(self.losses)
-        cur = torch.cuda.current_stream()
-        ts = self.teacher_stream if self.teacher_stream is not None else cur
-        ts.wait_stream(cur)
-        with torch.cuda.stream(ts), phase("fwd_teacher"):
-            pred_t, acts_t = self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
-        with phase("fwd_student"):
-            pred, acts = self.student.forward_nhwc(noisy, timesteps, ehs, B, H, W, train=backward)
-        cur.wait_stream(ts)
+        B, C, H, W = ctx.B, ctx.C, ctx.H, ctx.W
+        pred, (pred_t, acts_t) = ctx.pred, teacher_out
         M = B * H * W
         e_c, e_u = pred_t.t[:M], pred_t.t[M:]
         k.axpby(e_c, e_u, -1.0, 2.0)               # e_u <- 2 e_u - e_c  == e_u - (e_c - e_u)
@@ -379,28 +425,56 @@ class BilevelStepper:
             pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
             k.mse_bwd(pred.t, e_u, None, pred.g, B, H * W, C, cp, cp, cp, 2.0 * w["up_dist"] / n, False)
         if w["up_block"] > 0:
-            # the reference's teacher hooks hold the LAST teacher call (the unconditional one), trainer.py:2951-2954
-            self._block_loss_rows(acts, acts_t, B, w["up_block"], backward)
-        self.last_pred = pred
+            self._block_loss(ctx.acts, acts_t, B, w["up_block"], t_row0=M, seed=backward)
+
+    @property
+    def need_teacher(self):
+        return self.w["block"] > 0 or self.w["dist"] > 0
+
+    # ------------------------------------------------------------------ eager steps
+    def _beside(self, fn):
+        """Runs fn() on the teacher stream beside what the caller queues next; returns (result, join)."""
+        cur = torch.cuda.current_stream()
+        ts = self.teacher_stream
+        if ts is None:
+            return fn(), (lambda: None)
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            out = fn()
+        return out, (lambda: cur.wait_stream(ts))
+
+    def main_step(self, latents, noise, timesteps, prompt_embeds, backward=True, input_noise=None, teacher_out=None):
+        """latents/noise [B,4,H,W] fp32 (latents already x scaling_factor), timesteps int64 [B], prompt_embeds [B,T,ctx].
+        input_noise: the perturbed noise of `input_perturbation` (trainer.py:2416-2417, 2427-2428) - it enters the forward
+        process, while the target is formed from the clean `noise`.
+        teacher_out: (pred, acts) of `teacher_pass` on the same inputs, computed earlier (the teacher is then not run here).
+        Returns the device tensor [diff, dist, block, 0] (float64); total = w_diff*diff + w_block*block + w_dist*dist."""
+        if backward:
+            self.begin_wt_refresh()
+        join = lambda: None
+        if teacher_out is None and self.need_teacher:
+            teacher_out, join = self._beside(lambda: self.teacher_pass(latents, noise, timesteps, prompt_embeds, input_noise))
+        ctx = self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, input_noise=input_noise)
+        join()
+        self.main_loss_heads(ctx, teacher_out, backward)
         if backward:
             with phase("bwd"):
-                self._gscale = self._backward_and_reduce()
+                self._gscale = self.backward()
         return self.losses
 
-    def _block_loss_rows(self, acts_s, acts_t, B, weight, seed):
-        """Upper-step block term against the teacher's UNCONDITIONAL half (rows [M, 2M) of the 2B teacher batch)."""
-        seeded = set()
-        for key in BLOCK_KEYS:
-            a, b = acts_s[key], acts_t[key]
-            M, C = a.t.shape
-            bt = b.t[M:2 * M]
-            n = len(BLOCK_KEYS) * M * C
-            again = id(a) in seeded
-            if seed and not again:
-                a.g = torch.empty_like(a.t)
-                seeded.add(id(a))
-            k.mse_fwd_bwd(a.t, bt, None, self.losses, 2, a.g if seed else None, B, M // B, C, a.t.stride(0), bt.stride(0), C,
-                          1.0 / n, 2.0 * weight / n, again)
+    def upper_step(self, latents, noise, timesteps, prompt_embeds, empty_prompt_embeds, backward=True):
+        """Concept-suppression objective: w * mse(student(x_t, c), e_u - (e_c - e_u)) with the teacher's cond / uncond
+        predictions computed as ONE batch of 2B."""
+        if backward:
+            self.begin_wt_refresh()
+        tout, join = self._beside(lambda: self.upper_teacher_pass(latents, noise, timesteps, prompt_embeds, empty_prompt_embeds))
+        ctx = self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, want_target=False)
+        join()
+        self.upper_loss_heads(ctx, tout, backward)
+        if backward:
+            with phase("bwd"):
+                self._gscale = self.backward()
+        return self.losses
 
     def optimizer_step(self, upper=False, max_grad_norm=None):
         opt = self.upper_opt if upper else self.opt
@@ -420,58 +494,55 @@ class BilevelStepper:
         return w["diff"] * d + w["block"] * b + w["dist"] * s, d, s, b
 
 
-class GraphedBilevel:
-    """hipGraph replay of the bilevel iteration (launch-bound Python loop -> 4 captured graphs):
-         g_main  = forward diffusion + teacher fwd + student fwd/bwd + loss heads      (main step)
-         g_opt   = fused AdamW + weight-copy refresh                                   (main optimiser)
-         g_upper / g_uopt = the same for the concept-suppression step and its optimiser
-       Inputs are copied into static buffers; lr / bias corrections live in device scalars updated outside the graphs;
-       with world > 1 the bucketed RCCL all-reduce runs eagerly on its side stream between g_main and g_opt."""
+class _CapturedStep:
+    """The hipGraphs of one step kind: teacher (own memory pool: it runs beside `fwd`), fwd, and the loss heads + backward
+    cut into `len(bwd)` graphs; offs[i] = arena offset from which every gradient is final once bwd[i] has run."""
+    __slots__ = ("teacher", "fwd", "bwd", "offs", "keep")
 
-    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True, prefetch=None, teacher_group=None):
+    def all(self):
+        return ([self.teacher] if self.teacher is not None else []) + [self.fwd] + list(self.bwd)
+
+
+class GraphedBilevel:
+    """hipGraph replay of the bilevel iteration.  EVERY captured graph is a single-stream (linear) graph:
+
+         teacher  forward diffusion + frozen teacher forward          -> replayed on the teacher stream
+         fwd      forward diffusion + student forward                 -> main stream
+         bwd[i]   loss heads + the i-th share of the backward pass    -> main stream, after the teacher stream has joined
+
+       and everything that runs beside something else (teacher pass, dgrad-copy refresh, the AdamW of a finished share of the
+       gradient arena, with world > 1 the bucketed all-reduce in front of it) is ordered BETWEEN the graphs with stream
+       waits on the process-wide role streams.  A graph with parallel branches makes hipGraphLaunch (ROCm 7.2) walk
+       `GraphExec::parallel_streams_` in `hip::Graph::UpdateStreams`, which reads past the end of that vector when two of
+       the executor's own streams share the launch stream's hardware queue ("hipGraphLaunch fault"): graphs
+       with max_streams == 1 never enter that code.  Inputs are copied into static buffers; lr / bias corrections live in
+       device scalars updated outside the graphs."""
+
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True):
         self.st = stepper
         dev = stepper.dev
+        self.shape = (B, C, H, W, T, ctx)
         self.lat = torch.zeros(B, C, H, W, device=dev)
         self.noise = torch.zeros(B, C, H, W, device=dev)
         self.t = torch.zeros(B, dtype=torch.int64, device=dev)
         self.ehs = torch.zeros(B, T, ctx, device=dev)
         self.empty = torch.zeros(B, T, ctx, device=dev)
-        # Cross-step teacher prefetch (off by default; PDMK_TEACHER_PREFETCH=1 or prefetch=True): the frozen teacher's forward
-        # of the NEXT main batch is its own graph, replayed on the teacher stream beside this iteration's student forward AND
-        # backward; its outputs are copied into static buffers once this iteration's loss heads have read the previous ones.
-        # Measured on one MI355X (same-box A/B, DESIGN.md 5): no gain (159.3 img/s without, 157.0 with) - the GEMM kernels
-        # of the two streams each fill the CUs' LDS, so they do not co-run and the sum of kernel times is what counts.
-        need_teacher = stepper.w["block"] > 0 or stepper.w["dist"] > 0
-        self.prefetch = (os.environ.get("PDMK_TEACHER_PREFETCH", "0") == "1" if prefetch is None else prefetch) and \
-            need_teacher and stepper.teacher_stream is not None
-        # Teacher grouping (PDMK_TEACHER_GROUP=k or teacher_group=k, default 1 = off): the frozen teacher's forward of THIS
-        # batch and of the next k-1 announced main batches runs as ONE dense forward over k*B images (its own graph), and each
-        # of the k main steps copies its slice of the outputs into the static buffers the captured loss heads read.  The
-        # teacher does not depend on the student, so the arithmetic per image is unchanged - but its GEMMs have k times the
-        # rows, and at B = 8 the step is bound by what a small GEMM can take in per CU (DESIGN.md 5), not by FLOPs.
-        g_env = int(os.environ.get("PDMK_TEACHER_GROUP", "1"))
-        self.tgroup = max(1, int(teacher_group if teacher_group is not None else g_env)) if (need_teacher and not self.prefetch) else 1
-        if self.prefetch or self.tgroup > 1:
-            kb = self.tgroup * B
-            self.n_lat, self.n_noise = torch.zeros(kb, C, H, W, device=dev), torch.zeros(kb, C, H, W, device=dev)
-            self.n_t, self.n_ehs = torch.zeros(kb, dtype=torch.int64, device=dev), torch.zeros(kb, T, ctx, device=dev)
-        self._tslots = {}                    # teacher grouping: batch identity -> slot of the last grouped teacher pass
-        self.g_teach = self.g_tcopy = None
-        self.T_out = None                    # (pred Act, {key: Act}) static teacher outputs read by the captured loss heads
-        self._primed = None                  # identity of the batch the static teacher outputs currently belong to
-        self.g_main = self.g_opt = self.g_upper = self.g_uopt = None
+        self.g_main = self.g_upper = None
         self.segments = segments
-        self.force_segments = False          # tests: cut the backward into segments on a single rank as well
-        # AdamW of every finished sixth of the arena runs beside the rest of the backward (valid without gradient-norm
+        self.force_segments = False          # tests: cut the backward into segments on a single rank without streamed AdamW
+        # AdamW of every finished share of the arena runs beside the rest of the backward (valid without gradient-norm
         # clipping, which needs all gradients first; the shipped configs do not clip: trainer.py:2784-2786)
         self.stream_opt = stream_opt
-        self.opt_stream = torch.cuda.Stream(device=dev)
+        self.opt_stream = k.role_stream(dev, "opt")
+        self.cap_stream = k.role_stream(dev, "capture")
+        self.closed = False
 
     def _load(self, lat, noise, t, ehs, empty=None):
         self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
         if empty is not None:
             self.empty.copy_(empty)
 
+    # ------------------------------------------------------------------ capture
     def capture(self, bilevel=True):
         st = self.st
         st.defer_reduce = True
@@ -479,48 +550,26 @@ class GraphedBilevel:
         store = st.student.store
         opts = [o for o in (st.opt, st.upper_opt) if o is not None]
         snap = [store.master.clone(), store.grad.clone()] + [t_.clone() for o in opts for t_ in (o.m, o.v)]
-        # eager warm-up on a side stream (allocator + lazy tables), as torch.cuda.graphs requires.  It is also where the
-        # library times its GEMM candidates for every shape of the step (plan cache), so the static inputs hold random
-        # data for it: all-zero operands run at a higher clock and would rank the candidates differently.
+        # eager warm-up (allocator + lazy tables).  It is also where the library times its GEMM candidates for every shape
+        # of the step (plan cache), so the static inputs hold random data for it: all-zero operands run at a higher clock
+        # and would rank the candidates differently.
         gen = torch.Generator(device=self.lat.device).manual_seed(1234)
         for buf in (self.lat, self.noise, self.ehs, self.empty):
             buf.normal_(generator=gen)
         self.t.random_(0, 1000, generator=gen)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        ext = self.prefetch or self.tgroup > 1          # the teacher runs outside the main step's graph
-        if ext:
-            G_ = self.tgroup
-            for buf, src in ((self.n_lat, self.lat), (self.n_noise, self.noise), (self.n_t, self.t), (self.n_ehs, self.ehs)):
-                buf.copy_(src.repeat(G_, *([1] * (src.dim() - 1))))
-        with torch.cuda.stream(side):
-            if ext:                           # static teacher-output buffers (ONE batch), shaped by one eager pass
-                from ..models.unet.engine import Act
-                tp, ta = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
-                one = lambda a: torch.empty((a.t.shape[0] // self.tgroup, a.t.shape[1]), device=a.t.device, dtype=a.t.dtype)
-                self.T_out = (Act(one(tp), rg=False), {k_: Act(one(a), rg=False) for k_, a in ta.items()})
-                self._copy_teacher(tp, ta, 0)
-                del tp, ta
-            st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out)
+        cap = self.cap_stream
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            st.main_step(self.lat, self.noise, self.t, self.ehs)
             st.opt.launch(st._gscale)
             if bilevel:
                 st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty)
                 st.upper_opt.launch(st._gscale)
-        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
-        if ext:
-            self._capture_teacher()
-        self.g_main, self.main_offs = self._capture_step(
-            lambda: st.main_step(self.lat, self.noise, self.t, self.ehs, teacher_out=self.T_out), st.opt, cut_after_loss=self.prefetch)
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
-            st.opt.launch(st._gscale)
+        self.g_main = self._capture_step(upper=False)
         if bilevel:
-            self.g_upper, self.upper_offs = self._capture_step(
-                lambda: st.upper_step(self.lat, self.noise, self.t, self.ehs, self.empty), st.upper_opt)
-            self.g_uopt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_uopt, capture_error_mode="thread_local"):
-                st.upper_opt.launch(st._gscale)
+            self.g_upper = self._capture_step(upper=True)
         torch.cuda.synchronize()
         store.master.copy_(snap[0]); store.grad.copy_(snap[1])
         for i, o in enumerate(opts):
@@ -529,224 +578,150 @@ class GraphedBilevel:
         store.refresh()
         torch.cuda.synchronize()
 
-    def _copy_teacher(self, pred, acts, slot=0):
-        """Slot `slot` (one batch's rows) of the teacher pass's outputs -> the static buffers the loss heads read."""
-        dp, da = self.T_out
-        for src, dst in [(pred.t, dp.t)] + [(a.t, da[key].t) for key, a in acts.items()]:   # (dense teacher: no aliased keys)
-            rows = dst.shape[0]
-            k.copy2d(src[slot * rows:(slot + 1) * rows], dst, rows, src.shape[1], src.stride(0), dst.stride(0))
-
-    @staticmethod
-    def _batch_id(lat, noise, t, ehs):
-        """Identity of a batch for the `nxt` hand-over: same tensors, not modified in place since."""
-        return tuple((x.data_ptr(), x._version) for x in (lat, noise, t, ehs))
-
-    def _capture_teacher(self):
-        """g_teach = forward diffusion + teacher forward of the NEXT batch (own memory pool: it runs concurrently with the
-        student's graphs); g_tcopy = its outputs -> the static buffers the captured loss heads read."""
-        st = self.st
-        gc.collect()
-        torch.cuda.synchronize()
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        cap = torch.cuda.Stream()
-        cap.wait_stream(torch.cuda.current_stream())
-        try:
-            with torch.cuda.stream(cap):
-                self.g_teach = torch.cuda.CUDAGraph()
-                self.g_teach.capture_begin(capture_error_mode="thread_local")
-                self._t_live = st.teacher_pass(self.n_lat, self.n_noise, self.n_t, self.n_ehs)
-                self.g_teach.capture_end()
-                self.g_tslot = []                # one copy graph per slot of a grouped pass
-                for j in range(self.tgroup):
-                    gj = torch.cuda.CUDAGraph()
-                    gj.capture_begin(capture_error_mode="thread_local")
-                    self._copy_teacher(*self._t_live, j)
-                    gj.capture_end()
-                    self.g_tslot.append(gj)
-                self.g_tcopy = self.g_tslot[0]
-        finally:
-            if gc_was_on:
-                gc.enable()
-        torch.cuda.current_stream().wait_stream(cap)
-
-    def prime(self, lat, noise, t, ehs):
-        """Teacher outputs for a batch that was not announced as `next` by the previous main() (first iteration)."""
-        for buf, src in ((self.n_lat, lat), (self.n_noise, noise), (self.n_t, t), (self.n_ehs, ehs)):
-            buf.copy_(src)
-        self.g_teach.replay()
-        self.g_tcopy.replay()
-        self._primed = self._batch_id(lat, noise, t, ehs)
-
-    def _capture_step(self, fn, opt, cut_after_loss=False):
-        """Captures one step (forward + loss heads + backward [+ streamed AdamW]).  The tape is cut at block boundaries into
-        `self.segments` equal shares of the gradient arena (descending offsets).  world == 1: one graph; at every cut the
-        AdamW of the finished share is forked onto `opt_stream` (a parallel branch of the graph).  world > 1: one graph per
-        share, so that on replay the bucketed all-reduce (and then the AdamW) of a finished share runs on the comm stream
-        under the next segment.  Returns ([graphs], [arena offset final after each graph])."""
+    def _capture_step(self, upper):
+        """Captures one step kind as single-stream graphs.  The tape is cut at block boundaries into `nseg` equal shares of
+        the gradient arena (descending offsets): with world > 1 the bucketed all-reduce and then the AdamW of a finished
+        share run on the comm stream under the next graph; with world == 1 its AdamW runs on the opt stream."""
         st = self.st
         multi = st.world > 1 or self.force_segments
         nseg = self.segments if (multi or self.stream_opt) else 1
-        store = st.student.store
-        total = store.total
+        total = st.student.store.total
         cuts = [total * (nseg - 1 - i) // nseg for i in range(nseg - 1)]      # descending arena offsets
-        graphs, offs = [torch.cuda.CUDAGraph()], []
-        cap_stream = torch.cuda.Stream()
-        cap_stream.wait_stream(torch.cuda.current_stream())
-        state = {"hi": total, "n": 0}
-
-        def fork_adamw(lo):
-            self.opt_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.opt_stream):
-                opt.launch_range(lo, state["hi"], st._gscale)
-            state["hi"] = lo
+        cs = _CapturedStep()
+        cs.teacher, cs.bwd, cs.offs, cs.keep = None, [], [], []
+        need_t = upper or st.need_teacher
+        cap = self.cap_stream
+        state = {"n": 0}
 
         def seg_cb(off):
             if state["n"] < len(cuts) and off <= cuts[state["n"]]:
                 state["n"] += 1
                 st.student.engine.flush_pending()      # gradients in [off, total) are final only after this
-                if multi:
-                    graphs[-1].capture_end()
-                    offs.append(off)
-                    graphs.append(torch.cuda.CUDAGraph())
-                    graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
-                elif self.stream_opt:
-                    fork_adamw(off)
+                cs.bwd[-1].capture_end()
+                cs.offs.append(off)
+                cs.bwd.append(torch.cuda.CUDAGraph())
+                cs.bwd[-1].capture_begin(pool=cs.fwd.pool(), capture_error_mode="thread_local")
 
         st.segment_cb = seg_cb if nseg > 1 else None
-
-        def cut():       # teacher prefetch: graph boundary between the loss heads and the backward pass
-            if st._wt_pending:             # the dgrad-copy refresh forked at the top of the step joins inside this graph
-                torch.cuda.current_stream().wait_stream(st.wt_stream)
-                st._wt_pending = False
-            graphs[-1].capture_end()
-            offs.append(total)
-            graphs.append(torch.cuda.CUDAGraph())
-            graphs[-1].capture_begin(pool=graphs[0].pool(), capture_error_mode="thread_local")
-        st.after_loss_cb = cut if cut_after_loss else None
         # like torch.cuda.graph(): collect garbage first, and keep the collector off while capturing - destroying an old
         # CUDAGraph (or freeing its pool) from a GC pass in the middle of a capture aborts the process
         gc.collect()
         torch.cuda.synchronize()
         gc_was_on = gc.isenabled()
         gc.disable()
+        cap.wait_stream(torch.cuda.current_stream())
+        st.in_graph = True
         try:
-            with torch.cuda.stream(cap_stream):
-                graphs[0].capture_begin(capture_error_mode="thread_local")
-                fn()
-                if self.stream_opt and not multi:
-                    fork_adamw(0)
-                    torch.cuda.current_stream().wait_stream(self.opt_stream)
-                    store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
-                graphs[-1].capture_end()
+            with torch.cuda.stream(cap):
+                tout = None
+                if need_t:
+                    cs.teacher = torch.cuda.CUDAGraph()
+                    cs.teacher.capture_begin(capture_error_mode="thread_local")
+                    tout = (st.upper_teacher_pass(self.lat, self.noise, self.t, self.ehs, self.empty) if upper else
+                            st.teacher_pass(self.lat, self.noise, self.t, self.ehs))
+                    cs.teacher.capture_end()
+                cs.fwd = torch.cuda.CUDAGraph()
+                cs.fwd.capture_begin(capture_error_mode="thread_local")
+                ctx = st.student_forward(self.lat, self.noise, self.t, self.ehs, train=True, want_target=not upper)
+                cs.fwd.capture_end()
+                cs.bwd.append(torch.cuda.CUDAGraph())
+                cs.bwd[-1].capture_begin(pool=cs.fwd.pool(), capture_error_mode="thread_local")
+                (st.upper_loss_heads if upper else st.main_loss_heads)(ctx, tout, True)
+                st._gscale = st.backward()
+                cs.bwd[-1].capture_end()
+                cs.offs.append(0)
+                cs.keep = [tout, ctx]          # outputs the later graphs read: their storage must stay where it is
         finally:
+            st.in_graph = False
+            st.segment_cb = None
             if gc_was_on:
                 gc.enable()
-        offs.append(0)
-        st.segment_cb = None
-        st.after_loss_cb = None
-        torch.cuda.current_stream().wait_stream(cap_stream)
-        return graphs, offs
+        torch.cuda.current_stream().wait_stream(cap)
+        return cs
 
-    def _replay_step(self, graphs, offs, opt=None, teach=False):
-        """opt: the optimiser to stream (None = gradients only, the caller applies the optimiser).
-        teach: graphs[0] ends after the loss heads; the next batch's teacher graph runs on the teacher stream beside ALL of
-        `graphs` and publishes its outputs once graphs[0] (the reader of the current ones) has been queued."""
+    # ------------------------------------------------------------------ replay
+    def _replay_step(self, cs, opt=None):
+        """opt: the optimiser to apply (None = gradients only, the caller applies the optimiser)."""
         st = self.st
         store = st.student.store
         cur = torch.cuda.current_stream()
-        ts = st.teacher_stream
-
-        def after_first():
-            if teach:
-                ts.wait_stream(cur)              # the loss heads of this iteration have read the static teacher outputs
-                with torch.cuda.stream(ts):
-                    self.g_tcopy.replay()
-        if teach:
-            ts.wait_stream(cur)                  # the next batch's inputs are loaded
+        side = st.teacher_stream is not None
+        ts = st.teacher_stream if side else cur
+        if cs.teacher is not None:
+            if side:
+                ts.wait_stream(cur)              # inputs loaded; the previous step's loss heads have read the old outputs
             with torch.cuda.stream(ts):
-                self.g_teach.replay()
+                cs.teacher.replay()
+        st.begin_wt_refresh()                    # dgrad copies of the weights the last optimiser step wrote, beside the forward
+        cs.fwd.replay()
+        if cs.teacher is not None and side:
+            cur.wait_stream(ts)
+        st.join_wt_refresh()
+        fresh = store.dtype == torch.bfloat16
+        streamed = opt is not None and self.stream_opt
         if st.world == 1:
-            multi_forced = self.force_segments
-            for i, g in enumerate(graphs):
+            hi = store.total
+            for g, off in zip(cs.bwd, cs.offs):
                 g.replay()
-                if i == 0:
-                    after_first()
-            if opt is not None and self.stream_opt and multi_forced:          # forced segments on one rank (tests)
-                opt.launch_range(0, store.total, st._gscale)
-                store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
-            if teach:
-                cur.wait_stream(ts)
+                if streamed and len(cs.bwd) > 1 and not self.force_segments:
+                    self.opt_stream.wait_stream(cur)             # the share [off, hi) is final
+                    with torch.cuda.stream(self.opt_stream):
+                        opt.launch_range(off, hi, st._gscale)
+                    hi = off
+            if streamed:
+                if hi > 0:
+                    opt.launch_range(0, hi, st._gscale)
+                cur.wait_stream(self.opt_stream)
+                store.refresh(w_is_fresh=fresh, wt=not store.defer_wt)
             return
         red = st.reducer
         red.begin()
         done = store.total                       # AdamW has been issued for [done, total)
-        for i, (g, off) in enumerate(zip(graphs, offs)):
+        for g, off in zip(cs.bwd, cs.offs):
             g.replay()
-            if i == 0:
-                after_first()
-            red.ready_down_to(off)               # comm stream waits for the segment just queued, then all-reduces its share
-            if opt is not None and self.stream_opt and red.stream is not None and red.next_hi < done:
-                with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind it
+            red.ready_down_to(off)               # comm stream waits for the graph just queued, then reduces its whole buckets
+            if streamed and red.stream is not None and red.next_hi < done:
+                with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind them
                     opt.launch_range(red.next_hi, done, st._gscale)
                 done = red.next_hi
         red.finish()
-        if opt is not None and self.stream_opt:
+        if streamed:
             opt.launch_range(0, done, st._gscale)
-            store.refresh(w_is_fresh=store.dtype == torch.bfloat16, wt=not store.defer_wt)
-        if teach:
-            cur.wait_stream(ts)
+            store.refresh(w_is_fresh=fresh, wt=not store.defer_wt)
 
-    def _grouped_teacher(self, cur, upcoming):
-        """Teacher grouping: make the static teacher outputs hold `cur`'s.  If the last grouped pass did not cover it, run
-        one over [cur] + the next tgroup-1 announced batches (short lists are padded with cur)."""
-        bid = self._batch_id(*cur)
-        if not self._tslots.get(bid):
-            group = [cur] + [b for b in (upcoming or [])][: self.tgroup - 1]
-            self._tslots = {}
-            B = cur[0].shape[0]
-            for j in range(self.tgroup):
-                b = group[j] if j < len(group) else cur
-                for buf, src in zip((self.n_lat, self.n_noise, self.n_t, self.n_ehs), b):
-                    buf[j * B:(j + 1) * B].copy_(src)
-                if j < len(group):
-                    self._tslots.setdefault(self._batch_id(*b), []).append(j)
-            self.g_teach.replay()
-        # every slot serves ONE step: a batch that comes round again gets a fresh teacher pass (nothing is cached across uses)
-        self.g_tslot[self._tslots[bid].pop(0)].replay()
-
-    def main(self, lat, noise, t, ehs, nxt=None):
-        """One main step + its AdamW.  nxt = the (lat, noise, t, ehs) of the NEXT main() call - or, with teacher grouping,
-        a list of the next tgroup-1 of them.  Teacher prefetch: the next batch's teacher forward runs beside this step;
-        without nxt (or on the first call) the teacher outputs of THIS batch are computed up front (`prime`).  Teacher
-        grouping: one dense teacher forward serves this and the announced batches."""
-        lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches inside the step
+    def main(self, lat, noise, t, ehs):
+        """One main step + its AdamW."""
+        lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches of the step
         self._load(lat, noise, t, ehs)
-        teach = False
-        if self.tgroup > 1:
-            ups = None if nxt is None else ([nxt] if torch.is_tensor(nxt[0]) else list(nxt))
-            self._grouped_teacher((lat, noise, t, ehs), ups)
-        elif self.prefetch:
-            if nxt is not None and not torch.is_tensor(nxt[0]):
-                nxt = nxt[0]
-            if self._primed != self._batch_id(lat, noise, t, ehs):
-                self.prime(lat, noise, t, ehs)
-            if nxt is not None:
-                for buf, src in ((self.n_lat, nxt[0]), (self.n_noise, nxt[1]), (self.n_t, nxt[2]), (self.n_ehs, nxt[3])):
-                    buf.copy_(src)
-                teach = True
-                self._primed = self._batch_id(*nxt)
-            else:
-                self._primed = None
-        self._replay_step(self.g_main, self.main_offs, self.st.opt, teach=teach)
+        self._replay_step(self.g_main, self.st.opt)
         if not self.stream_opt:
-            self.g_opt.replay()
+            self.st.opt.launch(self.st._gscale)
         return lr
 
     def upper(self, lat, noise, t, ehs, empty):
         lr = self.st.upper_opt.prepare()
         self._load(lat, noise, t, ehs, empty)
-        self._replay_step(self.g_upper, self.upper_offs, self.st.upper_opt)
+        self._replay_step(self.g_upper, self.st.upper_opt)
         if not self.stream_opt:
-            self.g_uopt.replay()
+            self.st.upper_opt.launch(self.st._gscale)
         return lr
+
+    def close(self):
+        """Ordered teardown at a defined idle point: drain the device, destroy the executors (the pool owner `fwd` last),
+        release the static buffers.  Trainer calls this when a cached shape is evicted."""
+        if self.closed:
+            return
+        self.closed = True
+        torch.cuda.synchronize()
+        for cs in (self.g_upper, self.g_main):
+            if cs is None:
+                continue
+            cs.keep = []
+            for g in reversed(cs.bwd):
+                g.reset()
+            cs.bwd = []
+            if cs.teacher is not None:
+                cs.teacher.reset()
+            cs.fwd.reset()
+        self.g_main = self.g_upper = None
+        torch.cuda.synchronize()

@@ -86,8 +86,14 @@ class Trainer:
         # measures - captured forward / loss heads / segmented backward, AdamW streamed behind the bucketed all-reduce)
         # instead of eager launches.  Needs fixed batch shapes; no gradient clipping / input perturbation inside a graph.
         self.hip_graphs = bool(_cfg(config, "training.hip_graphs", _cfg(config, "hip_graphs", False)))
-        self._graphs = None
+        # captured steps by batch shape (the ragged last batch of an epoch has its own): a shape is captured once and kept;
+        # at most `training.hip_graph_shapes` (default 3) stay alive, the least recently used one is closed at an idle point
+        self._graphs = {}
         self._graph_lr = {}
+        if self.hip_graphs:
+            pert = float(_cfg(config, "model.prediction_model.input_perturbation", 0.0) or 0.0)
+            if self.max_grad_norm is not None or pert:
+                raise ValueError("training.hip_graphs does not support clip_grad_norm / input_perturbation (use eager mode)")
 
     # ---- frozen VAE (trainer.py:2128-2131, cast to the weight dtype :516-527); built on first use
     @property
@@ -283,12 +289,16 @@ class Trainer:
         if self.max_grad_norm is not None or self._input_noise is not None:
             raise ValueError("training.hip_graphs does not support clip_grad_norm / input_perturbation (use eager mode)")
         key = (tuple(lat.shape), tuple(ehs.shape))
-        if self._graphs is None or self._graphs[0] != key:
+        g = self._graphs.pop(key, None)
+        if g is None:
+            keep = max(1, int(_cfg(self.config, "training.hip_graph_shapes", 3)))
+            while len(self._graphs) >= keep:                 # evict the least recently used shape: ordered teardown, device idle
+                self._graphs.pop(next(iter(self._graphs))).close()
             B, C, H, W = lat.shape
             g = GraphedBilevel(self.stepper, B, C, H, W, ehs.shape[1], ehs.shape[2])
             g.capture(bilevel=self.bilevel)
-            self._graphs = (key, g)
-        return self._graphs[1]
+        self._graphs[key] = g                                # most recently used last
+        return g
 
     def step(self, batch, backward=True):
         lat, noise, t = self._sample(batch)
@@ -455,12 +465,19 @@ class UnetFineTuner(Trainer):
                 raise ValueError("training.max_train_steps is unset and the dataloader has no length")
             max_steps = int(_cfg(c, "training.num_train_epochs", 1)) * per_epoch
         max_steps = int(max_steps)
+        # update_train_steps (trainer.py:529-537): the epoch count is RE-derived from max_train_steps, so the loop below ends
+        # after ceil(max_train_steps / steps per epoch) passes over the dataloader - also when skipped (empty) batches left
+        # it short of max_train_steps.  A dataloader without a length has no epoch bound.
+        epochs = -(-max_steps // per_epoch) if per_epoch else None
         self.load_checkpoint()
+        # trainer.py:2744-2767: a resumed run starts at first_epoch = global_step // steps per epoch
+        first_epoch = self.global_step // per_epoch if (per_epoch and self.global_step) else 0
         upper_iter = iter(self.upper_dataloader) if self.bilevel else None
         pending = None
         t0 = time.time()
-        epoch = 0
-        while self.global_step < max_steps:          # for epoch in range(first_epoch, num_train_epochs), trainer.py:2769
+        epoch = first_epoch
+        # for epoch in range(first_epoch, num_train_epochs) (trainer.py:2769)
+        while self.global_step < max_steps and (epochs is None or epoch < epochs):
             stepped = False
             for batch in self.train_dataloader:
                 if self.global_step >= max_steps:
