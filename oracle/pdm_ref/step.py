@@ -88,26 +88,56 @@ def upper_loss_heads(pred, e_c, e_u, acts_s, acts_t, w_dist=1.0, w_block=0.0):
     return loss, torch.zeros(()), dist.detach(), block.detach()
 
 
-def main_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, w_diff=1.0, w_block=0.1, w_dist=2.0, gamma=5.0):
-    """student/teacher = (sd, info).  Returns (loss, diff, dist, block, pred) like trainer.py:2488."""
+class _mixed:
+    """`--mixed_precision bf16` as accelerate applies it to the reference trainer (trainer.py:516-527, 2730-2733; SURVEY
+    Appendix B.11): the frozen teacher's weights are CAST to bf16, the student keeps fp32 master weights and its forward runs
+    under torch.autocast(bfloat16) (here the CPU autocast: conv / linear / matmul in bf16, the loss heads on what comes out
+    of them - H1/H2 upcast with .float(), H3/H4 do not).  mixed=False: plain fp32."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def teacher_sd(self, sd):
+        if not self.on:
+            return sd
+        key = id(sd)
+        if _mixed._cache.get("key") != key:
+            _mixed._cache = {"key": key, "sd": {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in sd.items()}}
+        return _mixed._cache["sd"]
+
+    def ctx(self):
+        return torch.autocast("cpu", dtype=torch.bfloat16) if self.on else torch.autocast("cpu", enabled=False)
+
+    _cache = {}
+
+
+def main_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, w_diff=1.0, w_block=0.1, w_dist=2.0, gamma=5.0,
+                   mixed=False):
+    """student/teacher = (sd, info).  Returns (loss, diff, dist, block, pred) like trainer.py:2488.
+    mixed=True: the reference's `--mixed_precision bf16` numerics (see _mixed) instead of fp32."""
     noisy = add_noise(ac, latents, noise, t)
     target = get_velocity(ac, latents, noise, t)
     acts_t, acts_s = {}, {}
-    with torch.no_grad():
-        full = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, acts_t)
-    pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
+    mp = _mixed(mixed)
+    with mp.ctx():
+        with torch.no_grad():
+            full = unet_forward(mp.teacher_sd(teacher[0]), cfg, teacher[1], noisy, t, ehs, acts_t)
+        pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
     acts_s = {k: acts_s[k] for k in BLOCK_KEYS}
     loss, diff, dist, block = main_loss_heads(pred, target, full, acts_s, acts_t, ac, t, w_diff, w_block, w_dist, gamma)
     return loss, diff, dist, block, pred
 
 
-def upper_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, empty_ehs, w_dist=1.0, w_block=0.0):
+def upper_step_loss(student, teacher, cfg, ac, latents, noise, t, ehs, empty_ehs, w_dist=1.0, w_block=0.0, mixed=False):
     noisy = add_noise(ac, latents, noise, t)
     acts_t, acts_s = {}, {}
-    with torch.no_grad():
-        e_c = unet_forward(teacher[0], cfg, teacher[1], noisy, t, ehs, {})
-        e_u = unet_forward(teacher[0], cfg, teacher[1], noisy, t, empty_ehs, acts_t)   # the hooks hold the LAST call (uncond)
-    pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
+    mp = _mixed(mixed)
+    with mp.ctx():
+        tsd = mp.teacher_sd(teacher[0])
+        with torch.no_grad():
+            e_c = unet_forward(tsd, cfg, teacher[1], noisy, t, ehs, {})
+            e_u = unet_forward(tsd, cfg, teacher[1], noisy, t, empty_ehs, acts_t)   # the hooks hold the LAST call (uncond)
+        pred = unet_forward(student[0], cfg, student[1], noisy, t, ehs, acts_s)
     acts_s = {k: acts_s[k] for k in BLOCK_KEYS}
     loss, diff, dist, block = upper_loss_heads(pred, e_c, e_u, acts_s, acts_t, w_dist, w_block)
     return loss, diff, dist, block, pred

@@ -393,11 +393,13 @@ def _curve_inputs():
 _CURVE = {}
 
 
-def _oracle_curve(ocfg, dense, psd, info, lr, ulr):
+def _oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=False):
     """The same 9-iteration bilevel loop on the CPU oracle (autograd + its AdamW restatement); computed once per session
-    (it does not depend on the engine dtype under test)."""
-    if "ref" in _CURVE:
-        return _CURVE["ref"]
+    (it does not depend on the engine dtype under test).  mixed: the oracle in the reference's `--mixed_precision bf16`
+    numerics (bf16-cast teacher, student forward under autocast, fp32 master weights and optimiser)."""
+    key = "mixed" if mixed else "ref"
+    if key in _CURVE:
+        return _CURVE[key]
     from pdm_ref import step as ostep, weights as oweights
     ac = ostep.alphas_cumprod()
     P = {k_: v.clone() for k_, v in psd.items()}
@@ -408,15 +410,46 @@ def _oracle_curve(ocfg, dense, psd, info, lr, ulr):
         for name, oi in [("main", 0)] + ([("upper", 1)] if (it + 1) % 3 == 0 else []):
             Pg = {k_: v.clone().requires_grad_(True) for k_, v in P.items()}
             if name == "main":
-                loss = ostep.main_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs)[0]
+                loss = ostep.main_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, mixed=mixed)[0]
             else:
-                loss = ostep.upper_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, empty)[0]
-            loss.backward()
+                loss = ostep.upper_step_loss((Pg, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, empty, mixed=mixed)[0]
+            loss.float().backward()
             steps[oi] += 1
             ostep.adamw_step(P, {k_: v.grad for k_, v in Pg.items()}, mom[oi][0], mom[oi][1], steps[oi], lr if oi == 0 else ulr)
             ref.append(loss.item())
-    _CURVE["ref"] = ref
+    _CURVE[key] = ref
     return ref
+
+
+def test_bf16_curve_error_is_the_dtype_not_the_kernels(dev):
+    """north_star asks for loss curves within 1e-3 of the CPU reference; the fp32 engine meets that (test above), the bf16
+    engine cannot - and neither can the reference itself under `--mixed_precision bf16`.  The oracle in the reference's
+    mixed-precision numerics (trainer.py:516-527: bf16-cast teacher, student under autocast, fp32 master weights) gives the
+    distance a CORRECT bf16 implementation keeps from the fp32 curve; the HIP bf16 engine's curve must be no further from
+    the fp32 oracle than 1.5x that distance, at every one of the 12 points (against the largest oracle distance on the
+    curve: a single point's oracle distance can be ~0 by luck) and in the RMS over the curve."""
+    from pdm.training.bilevel import BilevelStepper
+    ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16, drop_depth=(1, 9))
+    lr, ulr = 2e-5, 5e-5
+    ref = _oracle_curve(ocfg, dense, psd, info, lr, ulr)
+    mix = _oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=True)
+    st = BilevelStepper(student, teacher, lr=lr, upper_lr=ulr, bilevel=True)
+    hip = []
+    for it, (lat, noise, t, ehs, empty) in enumerate(_curve_inputs()):
+        for name in ["main"] + (["upper"] if (it + 1) % 3 == 0 else []):
+            if name == "main":
+                L = st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+            else:
+                L = st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda())
+            st.optimizer_step(upper=name == "upper")
+            hip.append(st.total(L, upper=name == "upper")[0])
+    rel = lambda a: [abs(x - r) / max(abs(r), 1e-6) for x, r in zip(a, ref)]
+    d_mix, d_hip = rel(mix), rel(hip)
+    assert max(d_mix) > 1e-4, d_mix                           # the mixed oracle really computes in bf16
+    rms = lambda d: (sum(x * x for x in d) / len(d)) ** 0.5
+    report = [(round(a, 5), round(b, 5)) for a, b in zip(d_hip, d_mix)]
+    assert max(d_hip) <= 1.5 * max(d_mix), report
+    assert rms(d_hip) <= 1.5 * rms(d_mix), (rms(d_hip), rms(d_mix), report)
 
 
 def test_deferred_wt_refresh_is_complete_before_backward(dev):

@@ -70,7 +70,7 @@ class UNetEngine:
         # (eager mode only, opt-in, measured slower once the ring kernels own the LDS: PDMK_WGRAD_ASYNC=1; never under
         # stream capture - captured graphs are single-stream, bilevel.py GraphedBilevel)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
-        self.wgrad_stream = k.role_stream(self.dev, "wgrad") if self.wgrad_async else None
+        self.wgrad_stream = None          # the dedicated "wgrad" role stream, created on first use
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -119,20 +119,22 @@ class UNetEngine:
             fn()
             return
         main = torch.cuda.current_stream()
+        if self.wgrad_stream is None:
+            self.wgrad_stream = k.role_stream(self.dev, "wgrad")
         self.wgrad_stream.wait_stream(main)
         with torch.cuda.stream(self.wgrad_stream):
             fn()
         self._keep.extend(operands)
 
     def _join_wgrad(self):
-        if self.wgrad_async and self._keep:
+        if self.wgrad_async and self._keep and self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._keep.clear()
 
     def _wgrad_fence(self):
         """The gradient buffer a side-stream wgrad is reading is about to be handed on (aliased) and accumulated into
         in place by later main-stream kernels: make the main stream wait for the side stream first."""
-        if self.wgrad_async:
+        if self.wgrad_async and self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     def flush_pending(self):

@@ -305,17 +305,17 @@ class BilevelStepper:
     def _ehs2d(self, e):
         return e.to(self.dev).to(self.student.dtype).reshape(e.shape[0] * e.shape[1], e.shape[2]).contiguous()
 
-    def _block_loss(self, acts_s, acts_t, B, weight, t_row0=0, seed=True):
-        """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds; t_row0: first teacher row
-        (the upper step reads the UNCONDITIONAL half of the 2B teacher batch: the reference's teacher hooks hold the last
-        teacher call, trainer.py:2951-2954)."""
+    def _block_loss(self, acts_s, acts_t, B, weight, uncond_half=False, seed=True):
+        """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds; uncond_half: the upper step
+        reads the UNCONDITIONAL half (rows [M, 2M) of every activation) of the 2B teacher batch - the reference's teacher
+        hooks hold the last teacher call, trainer.py:2951-2954."""
         # when every layer of a block is dropped and it has no sampler, two hook keys hold the SAME activation (e.g. both
         # resnets of down_blocks.3 dropped: acts['d3'] is acts['d2']): its gradient seed is the sum of both terms
         seeded = set()
         for key in BLOCK_KEYS:
             a, b = acts_s[key], acts_t[key]
             M, C = a.t.shape
-            bt = b.t[t_row0:t_row0 + M]
+            bt = b.t[M:2 * M] if uncond_half else b.t[:M]
             n = len(BLOCK_KEYS) * M * C
             again = id(a) in seeded
             if seed and weight > 0 and not again:
@@ -425,7 +425,7 @@ class BilevelStepper:
             pred.g = k.zeros(tuple(pred.t.shape), pred.t.device, pred.t.dtype)
             k.mse_bwd(pred.t, e_u, None, pred.g, B, H * W, C, cp, cp, cp, 2.0 * w["up_dist"] / n, False)
         if w["up_block"] > 0:
-            self._block_loss(ctx.acts, acts_t, B, w["up_block"], t_row0=M, seed=backward)
+            self._block_loss(ctx.acts, acts_t, B, w["up_block"], uncond_half=True, seed=backward)
 
     @property
     def need_teacher(self):
