@@ -318,6 +318,7 @@ def main():
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
         if graphs is not None:
             extras["graphs_per_main_step"] = len(graphs.g_main.all())
+        extras["lockstep_forward"] = bool(st.lockstep)
         if world == 1 and not a.no_vae and not a.tiny:
             # SURVEY 8f N1, NOT part of `value` (SURVEY 8d keeps the VAE off the timed path): what a pixel_values batch adds
             # in front of every step - vae.encode(pixels).latent_dist.sample() * 0.18215 (trainer.py:2405-2406)
@@ -364,6 +365,8 @@ def main():
             with open(os.environ["PDMK_DUMP_GEMM"], "w") as f:
                 for kind, flops, e0, e1, shp in prof:
                     f.write(json.dumps({"kind": list(kind), "flops": flops, "ms": e0.elapsed_time(e1), "mnk_sk": shp}) + "\n")
+        extras["gemm_launches_main_step"] = len(prof)
+        extras["gemm_problems_in_grouped_launches"] = sum(kd[4] for kd, *_ in prof if len(kd) > 4 and kd[4] > 1)
         agg, cls = {}, {}
         for kind, flops, e0, e1, shp in prof:
             ms = e0.elapsed_time(e1)
@@ -378,8 +381,13 @@ def main():
         # strings it prints for the two weight-gradient instantiations are kept here to look their PMC traffic up
         legacy_sym = {(2, 1): "igemm_kernel<bool _Accum, int, EL, int, E, 0, 8, 8>",
                       (2, 2): "_ZN12_GLOBAL__N_112igemm_kernelIDF16bLi2ELi2ELi0ELi8ELi8EEEv14pdmk_gemm_argsiijj"}
-        sym = lambda kd: (k.candidate_name(kd[1], kd[2], kd[3]) if kd[3] > 0 else
-                          f"igemm_kernel<__bf16, {kd[1]}, {kd[2]}, 0, 8, 8> [rocprofv3: {legacy_sym.get(kd[1:3], 'igemm_kernel / pdmk_dma::igemm_dma_kernel')}]")
+        def sym(kd):
+            if kd[3] <= 0:
+                return (f"igemm_kernel<__bf16, {kd[1]}, {kd[2]}, 0, 8, 8> [rocprofv3: "
+                        f"{legacy_sym.get(kd[1:3], 'igemm_kernel / pdmk_dma::igemm_dma_kernel')}]")
+            name = k.candidate_name(kd[1], kd[2], kd[3])
+            # a grouped launch (pdmk_gemm_group: several problems in one grid) runs the _group_kernel instantiation
+            return name.replace("_kernel<", "_group_kernel<") if (len(kd) > 4 and kd[4] > 1) else name
         dom = max(agg.items(), key=lambda kv: kv[1][1])
         ach = dom[1][0] / (dom[1][1] * 1e-3) / 1e12
 
@@ -393,25 +401,31 @@ def main():
             t_m = t_h = t_r = t_meas = t_i = t_3 = 0.0
             n_h = n_i = 0
             b_tot = 0.0
-            for kind, flops, e0, e1, (M, N, K, sk) in entries:
+            for kind, flops, e0, e1, shp in entries:
                 conv_a, wg = kind[1] == 1, kind[1] == 2
-                if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
-                    byts = esz * (K * M + K * (N // 9 if kind[2] == 2 else N)) + 4 * M * N
-                else:
-                    byts = esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
-                tm, th = 2.0 * M * N * K / pk, byts / 8e12
+                members = shp if isinstance(shp, list) else [shp]       # a grouped launch lists its problems
+                byts = mflop = 0.0
+                ti = 0.0
+                for (M, N, K, sk) in members:
+                    if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
+                        byts += esz * (K * M + K * (N // 9 if kind[2] == 2 else N)) + 4 * M * N
+                    else:
+                        byts += esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
+                    mflop += 2.0 * M * N * K
+                    # third side: what a CU can take in from L2 into LDS (~70 GB/s per CU, 18 TB/s chip-wide: MI355X_MICROARCH.md
+                    # "Indexed rows: gather into LDS", tools/small_gemm_sweep.py).  An output tile BM x BN needs (BM + BN) K
+                    # operand elements whatever the kernel (a halo-staged 3x3 conv reads its activation patch once per 9 taps);
+                    # best case over the tile shapes a 512-thread workgroup can hold, with tiles spread over 256 CUs
+                    tim = float("inf")
+                    for bm in (64, 128, 256):
+                        for bn in (64, 128, 160, 256):
+                            tiles = -(-M // bm) * -(-N // bn)
+                            a_el = bm * (K / 9.0 if (conv_a or (wg and kind[2] == 2)) else K)
+                            per_cu = -(-tiles // 256) * (a_el + bn * K) * esz
+                            tim = min(tim, per_cu / 70e9)
+                    ti += tim
+                tm, th = mflop / pk, byts / 8e12
                 b_tot += byts
-                # third side: what a CU can take in from L2 into LDS (~70 GB/s per CU, 18 TB/s chip-wide: MI355X_MICROARCH.md
-                # "Indexed rows: gather into LDS", tools/small_gemm_sweep.py).  An output tile BM x BN needs (BM + BN) K
-                # operand elements whatever the kernel (a halo-staged 3x3 conv reads its activation patch once per 9 taps);
-                # best case over the tile shapes a 512-thread workgroup can hold, with tiles spread over 256 CUs
-                ti = float("inf")
-                for bm in (64, 128, 256):
-                    for bn in (64, 128, 160, 256):
-                        tiles = -(-M // bm) * -(-N // bn)
-                        a_el = bm * (K / 9.0 if (conv_a or (wg and kind[2] == 2)) else K)
-                        per_cu = -(-tiles // 256) * (a_el + bn * K) * esz
-                        ti = min(ti, per_cu / 70e9)
                 t_m, t_h, t_i = t_m + tm, t_h + th, t_i + ti
                 t_r, t_3 = t_r + max(tm, th), t_3 + max(tm, th, ti)
                 n_h += th > tm

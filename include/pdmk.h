@@ -100,6 +100,18 @@ typedef struct pdmk_gemm_args {
 #define PDMK_EPI_GEGLU 1
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
+/* Up to PDMK_GEMM_GROUP_MAX INDEPENDENT GEMMs (no problem reads what another writes) in ONE launch where the library has a
+ * kernel shape that serves them all: the linear workgroup id of the grid maps to (problem, tile, split), so the launch is as
+ * long as the problems together and pays one kernel boundary.  What it replaces: the frozen teacher's and the student's
+ * forward run the same layer sequence on independent data (pdm/training/trainer.py:2446-2459, 2951-2954) - layer l of both
+ * is one call; and the weight gradients of consecutive layers of a block (blocks.py via accelerator.backward,
+ * trainer.py:2782, 2808) are one call each group.  Every problem is validated exactly as by pdmk_gemm and produces
+ * BIT-IDENTICAL results to its own pdmk_gemm call with the same kernel shape; problems the grouped kernels do not take (fp32,
+ * K-step-32 / row-block plans) and groups that measured slower than their separate launches are launched one by one.  The first time a group of shapes is
+ * seen outside stream capture the library times {grouped with each member's planned shape, separate} and caches the choice.
+ * *grouped_out (optional): number of problems that went out in a multi-problem launch. */
+#define PDMK_GEMM_GROUP_MAX 4
+int pdmk_gemm_group(const pdmk_gemm_args* args, int n, pdmk_stream stream, int32_t* grouped_out);
 /* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller
  * should use (1 = plain call; > 1 = accumulate fp32 partials into a zeroed [M,N] workspace with out_f32 + splitk, then
  * pdmk_splitk_finish).  The first time a shape is seen outside stream capture the library times its candidate kernels

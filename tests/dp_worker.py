@@ -71,7 +71,7 @@ def run(mode, world, rank, out=None):
         graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True)
         graphs.force_segments = True            # world 1 takes the multi-graph replay path too
         graphs.capture(bilevel=True)
-        assert len(graphs.g_main.bwd) == 3 and graphs.g_main.teacher is not None
+        assert len(graphs.g_main.bwd) == 3 and graphs.g_main.teacher is not None      # fp32 engine: no lockstep
         assert torch.equal(store.master, init)  # capture restored the training state
     # ---- gradient of the first main step, reduced over the ranks, no optimiser
     d = data[ITERS]

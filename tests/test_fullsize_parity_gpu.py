@@ -282,7 +282,7 @@ def test_benchmarked_configuration_matches_oracle(dev, tmp_path):
     st = BilevelStepper(student, teacher)
     gr = GraphedBilevel(st, B, 4, 64, 64, 77, 1024)
     gr.capture(bilevel=True)
-    assert len(gr.g_main.bwd) >= 2 and gr.g_main.teacher is not None
+    assert len(gr.g_main.bwd) >= 2 and (gr.g_main.teacher is None) == st.lockstep
     store = student.store
     # ---- main step: gradients only (no optimiser), replayed twice (the second replay must not see stale state)
     for _ in range(2):

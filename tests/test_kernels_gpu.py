@@ -3,6 +3,7 @@ statement of the same op on identical inputs.  Tolerances: fp32 path 2e-4 of the
 fmaf chain; only summation order differs); bf16 path 2e-2 of the output scale against fp32 math on the bf16-rounded
 inputs (bf16 storage of outputs/intermediates, fp32 accumulation)."""
 import math
+import os
 
 import pytest
 import torch
@@ -879,3 +880,156 @@ def test_comm_handle_single_rank_allreduce(dev):
     comm.close()
     with pytest.raises(k.PdmkError):
         k.Comm(uid, 3, 2)                       # rank outside the world
+
+
+def _unforce():
+    for var in ("PDMK_RING_CFG", "PDMK_WGRAD_CFG"):
+        os.environ.pop(var, None)
+
+
+def _group_call(k, recs_fn, n_expected, cand, monkey_env):
+    """Runs recs_fn() (which issues k.gemm calls) under a Recorder and sends the records through pdmk_gemm_group with the
+    grouped candidate forced; returns how many problems went out in the multi-problem launch."""
+    with k.Recorder() as r:
+        recs_fn()
+    assert len(r.recs) == n_expected and all(x.kind == "gemm" for x in r.recs)
+    os.environ["PDMK_GROUP_CFG"] = str(cand)
+    try:
+        return k.gemm_group(r.recs)
+    finally:
+        del os.environ["PDMK_GROUP_CFG"]
+
+
+@pytest.mark.parametrize("cand", [1, 3, 6, 7, 9, 12, 17, 19])
+def test_gemm_group_linear_bit_equal_to_separate(dev, force_cfg, cand):
+    """pdmk_gemm_group: 2, 3 and 4 independent Linear problems of DIFFERENT ragged shapes (bias / residual / accumulate /
+    strided rows / fused GEGLU mixed) in one launch of ring candidate `cand` == the same problems launched one by one with
+    that candidate, bit for bit; and vs fp32 math.  This is what runs teacher layer l and student layer l as one launch."""
+    from pdm import _pdmk as k
+    torch.manual_seed(cand)
+    dt = torch.bfloat16
+    probs = []
+    for (M, N, K, bias, res, acc, geglu) in [(515, 320, 320, True, True, False, False), (200, 136, 96, False, False, True, False),
+                                             (1000, 416, 64, True, False, False, True), (77, 64, 1024, True, True, False, False)]:
+        A, W = rnd((M, K), dev, dt), rnd((N, K), dev, dt, 0.1)
+        b = rnd((N,), dev, torch.float32) if bias else None
+        R = rnd((M, N + 8), dev, dt) if res else None
+        ld = (N // 2 if geglu else N) + 16
+        C0 = rnd((M, ld), dev, dt)
+        probs.append((M, N, K, A, W, b, R, acc, geglu, C0))
+
+    def issue(outs, f_outs):
+        for (M, N, K, A, W, b, R, acc, geglu, C0), C, F_ in zip(probs, outs, f_outs):
+            if geglu:
+                assert k.gemm_geglu(A, W, C[:, :N // 2], F_, M, N, K, K, K, bias=b)
+            else:
+                k.gemm(A, W, C[:, :N], M, N, K, K, K, C.stride(0), bias=b, R=R[:, :N] if R is not None else None,
+                       ldr=R.stride(0) if R is not None else 0, accumulate=acc)
+    for n in (2, 3, 4):
+        force_cfg("PDMK_RING_CFG", cand)
+        sep = [p[9].clone() for p in probs[:n]]
+        sep_f = [torch.zeros(p[0], p[1], device=dev, dtype=dt) if p[8] else None for p in probs[:n]]
+        pr = probs
+        probs = pr[:n]
+        issue(sep, sep_f)
+        torch.cuda.synchronize()
+        _unforce()
+        grp = [p[9].clone() for p in probs]
+        grp_f = [torch.zeros(p[0], p[1], device=dev, dtype=dt) if p[8] else None for p in probs]
+        got = _group_call(k, lambda: issue(grp, grp_f), n, cand, None)
+        torch.cuda.synchronize()
+        probs = pr
+        assert got == n, (cand, n, got)
+        for a_, b_ in zip(sep, grp):
+            assert torch.equal(a_, b_), (cand, n)
+        for a_, b_ in zip(sep_f, grp_f):
+            assert a_ is None or torch.equal(a_, b_)
+    # and against fp32 math (first problem)
+    M, N, K, A, W, b, R, acc, geglu, C0 = probs[0]
+    ref = A.float() @ W.float().t() + b + R[:, :N].float()
+    close(grp[0][:, :N].float(), ref, 2e-2, "group vs fp32")
+
+
+@pytest.mark.parametrize("cand", [13, 14, 15, 16, 3, 12])
+def test_gemm_group_conv_bit_equal_to_separate(dev, force_cfg, cand):
+    """Grouped stride-1 3x3 convs (halo kernels 13-16; ring kernels 3 / 12 gather per tap): a dense and a pruned layer of one
+    level, different channel counts, per-image time-embedding row / residual - one launch == separate launches."""
+    from pdm import _pdmk as k
+    torch.manual_seed(100 + cand)
+    dt = torch.bfloat16
+    B, H = 2, 16
+    probs = []
+    for (Ci, Co, rowvec, res) in [(64, 160, True, False), (96, 64, False, True), (32, 320, False, False)]:
+        x, w = rnd((B * H * H, Ci), dev, dt), rnd((Co, 9 * Ci), dev, dt, 0.05)
+        rv = rnd((B, Co), dev, torch.float32) if rowvec else None
+        R = rnd((B * H * H, Co), dev, dt) if res else None
+        probs.append((Ci, Co, x, w, rnd((Co,), dev, torch.float32), rv, R))
+
+    def issue(outs):
+        for (Ci, Co, x, w, b, rv, R), y in zip(probs, outs):
+            k.gemm(x, w, y, B * H * H, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(B, H, H, Ci, H, H, 0, Ci), bias=b,
+                   rowvec=rv, rows_per_b=H * H, ldrv=Co if rv is not None else 0, R=R, ldr=Co if R is not None else 0)
+    force_cfg("PDMK_RING_CFG", cand)
+    sep = [torch.zeros(B * H * H, p[1], device=dev, dtype=dt) for p in probs]
+    issue(sep)
+    torch.cuda.synchronize()
+    _unforce()
+    grp = [torch.zeros(B * H * H, p[1], device=dev, dtype=dt) for p in probs]
+    got = _group_call(k, lambda: issue(grp), 3, cand, None)
+    torch.cuda.synchronize()
+    assert got == 3, (cand, got)
+    for a_, b_ in zip(sep, grp):
+        assert torch.equal(a_, b_), cand
+    Ci, Co, x, w, b, rv, R = probs[0]
+    ref = F.conv2d(x.float().view(B, H, H, Ci).permute(0, 3, 1, 2), w.float().view(Co, 3, 3, Ci).permute(0, 3, 1, 2), b, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * H, Co) + rv.repeat_interleave(H * H, 0)
+    close(grp[0].float(), ref, 2e-2, "group conv vs fp32")
+
+
+@pytest.mark.parametrize("cand", [1, 2, 3, 4, 5, 6, 7])
+def test_gemm_group_wgrad_matches_separate(dev, force_cfg, cand):
+    """Grouped weight gradients (Linear: ring candidates 1-5; conv: 1-5 and the halo kernels 6 / 7), slab mode (plain stores:
+    bit-equal to separate launches) with different split factors per problem, bias gradient fused."""
+    from pdm import _pdmk as k
+    torch.manual_seed(200 + cand)
+    dt = torch.bfloat16
+    conv = cand >= 6
+    B, H = 2, 16
+    P = B * H * H
+    probs = []
+    for (No, Ki, sk) in ([(64, 64, 2), (128, 96, 4), (160, 32, 1)] if conv else [(320, 320, 4), (160, 96, 2), (64, 1024, 3)]):
+        dy, x = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
+        probs.append((No, Ki, sk, dy, x))
+
+    def issue(outs, cs):
+        for (No, Ki, sk, dy, x), ws, c in zip(probs, outs, cs):
+            if conv:
+                k.gemm(dy, x, ws, No, 9 * Ki, P, No, 0, 9 * Ki, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, out_f32=True, splitk=sk,
+                       accumulate=2 if sk > 1 else 0, conv=(B, H, H, Ki, H, H, 0, Ki), dtype=k.BF16, colsum_out=c)
+            else:
+                k.gemm(dy, x, ws, No, Ki, P, No, Ki, Ki, a_mode=k.A_COLK, b_mode=k.B_COLK, out_f32=True, splitk=sk,
+                       accumulate=2 if sk > 1 else 0, dtype=k.BF16, colsum_out=c)
+    mk = lambda: ([torch.zeros(p[2] * p[0] * (9 if conv else 1) * p[1], device=dev) for p in probs],
+                  [torch.zeros(p[0], device=dev) for p in probs])
+    force_cfg("PDMK_WGRAD_CFG", cand)
+    sep, sep_c = mk()
+    issue(sep, sep_c)
+    torch.cuda.synchronize()
+    _unforce()
+    grp, grp_c = mk()
+    got = _group_call(k, lambda: issue(grp, grp_c), 3, cand, None)
+    torch.cuda.synchronize()
+    assert got == 3, (cand, got)
+    for a_, b_ in zip(sep, grp):
+        assert torch.equal(a_, b_), cand
+    for a_, b_ in zip(sep_c, grp_c):
+        assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-5)          # bias gradient: fp32 atomics over the splits
+    No, Ki, sk, dy, x = probs[0]
+    got0 = grp[0].view(sk, No, -1).sum(0)
+    if conv:
+        xi = x.float().view(B, H, H, Ki).permute(0, 3, 1, 2)
+        cols = torch.nn.functional.unfold(xi, 3, padding=1).view(B, Ki, 9, H * H).permute(0, 3, 2, 1).reshape(P, 9 * Ki)
+        ref = dy.float().t() @ cols
+    else:
+        ref = dy.float().t() @ x.float()
+    close(got0, ref, 2e-2, "group wgrad vs fp32")

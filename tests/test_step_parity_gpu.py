@@ -238,7 +238,7 @@ def test_segmented_graph_replay_matches_eager(dev):
         g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=nseg, stream_opt=False)
         g.force_segments = nseg > 1
         g.capture(bilevel=False)
-        assert len(g.g_main.bwd) == nseg and g.g_main.teacher is not None, (len(g.g_main.bwd), g.g_main.offs)
+        assert len(g.g_main.bwd) == nseg and (g.g_main.teacher is None) == st.lockstep, (len(g.g_main.bwd), g.g_main.offs)
         student.store.grad.zero_()
         g._load(lat, noise, t, ehs)
         g._replay_step(g.g_main)
@@ -305,7 +305,7 @@ def test_graph_replay_with_teacher_graph_matches_eager_and_survives_recapture(de
         if mode == "graph":
             gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3)
             gr.capture(bilevel=True)
-            assert gr.g_main.teacher is not None and gr.g_upper.teacher is not None and len(gr.g_main.bwd) >= 2
+            assert not st.lockstep and gr.g_main.teacher is not None and gr.g_upper.teacher is not None and len(gr.g_main.bwd) >= 2
         losses = []
         for i, b in enumerate(batches):
             if mode == "graph":
@@ -492,3 +492,41 @@ def test_deferred_wt_refresh_is_complete_before_backward(dev):
     torch.cuda.synchronize()
     assert torch.allclose(store.grad, g_now, rtol=0, atol=1e-6 * float(g_now.abs().max()) + 1e-12) or \
         torch.nn.functional.cosine_similarity(store.grad, g_now, dim=0).item() > 0.99999
+
+
+def test_lockstep_forward_matches_two_stream_forward(dev):
+    """PDMK_LOCKSTEP=1: teacher pass and student forward recorded and issued side by side on one stream, layer pairs through
+    pdmk_gemm_group (bit-identical to separate launches by the kernel tests); losses, gradients and the parameter update of a
+    main and an upper step equal the two-stream mode's, eager and as graph replay."""
+    from pdm import _pdmk as k
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
+    lat, noise, t, ehs, empty = (x.cuda() for x in _inputs())
+    res = []
+    for mode in ("streams", "lockstep", "lockstep_graph"):
+        ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16, drop_depth=(1, 9))
+        st = BilevelStepper(student, teacher, lr=1e-3, upper_lr=1e-3)
+        st.lockstep = mode != "streams"
+        if mode == "lockstep_graph":
+            g = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=2)
+            g.capture(bilevel=True)
+            assert g.g_main.teacher is None and g.g_upper.teacher is None          # one forward graph for both models
+            g._load(lat, noise, t, ehs)
+            g._replay_step(g.g_main, None)
+        else:
+            k.STATS.update(launches=0, grouped=0)
+            st.main_step(lat, noise, t, ehs)
+            if mode == "lockstep":
+                assert k.STATS["launches"] > 50, k.STATS                            # the recorded path really ran
+        torch.cuda.synchronize()
+        grad, losses = student.store.grad.clone(), st.losses.clone()
+        k.zero_(student.store.grad)
+        if mode == "lockstep_graph":
+            g._load(lat, noise, t, ehs, empty)
+            g._replay_step(g.g_upper, None)
+        else:
+            st.upper_step(lat, noise, t, ehs, empty)
+        torch.cuda.synchronize()
+        res.append((losses, grad, st.losses.clone(), student.store.grad.clone()))
+    for other in res[1:]:
+        for a, b in zip(other, res[0]):
+            assert torch.allclose(a.double(), b.double(), rtol=2e-2, atol=2e-2 * float(b.abs().max())), (a - b).abs().max()

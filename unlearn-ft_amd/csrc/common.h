@@ -59,6 +59,17 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Kernel-argument block of a grouped GEMM launch (pdmk_gemm_group): problem i owns the linear workgroup ids
+// [start[i], start[i] + gx[i] * gy[i]) (start[] are multiples of 8; the gap is padding workgroups that exit at once).
+struct pdmk_gemm_group_dev {
+    int n;
+    int start[PDMK_GEMM_GROUP_MAX + 1];
+    int gx[PDMK_GEMM_GROUP_MAX], gy[PDMK_GEMM_GROUP_MAX];          // tiles, splits of the problem
+    unsigned a_bytes[PDMK_GEMM_GROUP_MAX], b_bytes[PDMK_GEMM_GROUP_MAX];
+    int aux0[PDMK_GEMM_GROUP_MAX], aux1[PDMK_GEMM_GROUP_MAX];       // halo conv: tile width; conv weight gradient: lg(wo), lg(ho wo)
+    pdmk_gemm_args p[PDMK_GEMM_GROUP_MAX];
+};
+
 // MFMA traits.  A 16x16 output tile per instruction; lane l: C[row=(l>>4)*4+r][col=l&15], r=0..3.
 //   bf16: v_mfma_f32_16x16x32_bf16, lane l holds A[row l&15][k=8(l>>4)+j], B[k=8(l>>4)+j][col l&15], j=0..7
 //   f32 : v_mfma_f32_16x16x4_f32  , lane l holds A[row l&15][k=l>>4],       B[k=l>>4][col l&15]      (exact fp32)

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -724,9 +725,9 @@ int heuristic_sk(const pdmk_gemm_args& g) {           // untuned default: split 
 
 }  // namespace
 
-extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
-    if (!a || !a->A || !a->B || !a->C) return -1;
-    const pdmk_gemm_args& g = *a;
+// argument validation shared by pdmk_gemm and pdmk_gemm_group (0 = ok)
+static int validate_args(const pdmk_gemm_args& g) {
+    if (!g.A || !g.B || !g.C) return -1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return -1;
     const int ch = g.dtype == PDMK_BF16 ? 8 : 4;     // elements per 16 bytes
     const int g4 = 4 * ch;                             // a thread moves up to 64 contiguous bytes: 32 bf16 / 16 fp32
@@ -763,6 +764,13 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
             return -1;
         if (!ring_mode()) return -2;
     }
+    return 0;
+}
+
+extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
+    if (!a) return -1;
+    const pdmk_gemm_args& g = *a;
+    if (const int vrc = validate_args(g)) return vrc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_last_candidate = 0;
     if (!(ring_eligible(g) && (g.K % 8) == 0) && !wgrad_eligible(g)) return launch_legacy(g, st);
@@ -793,6 +801,185 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (g.epilogue && rc == 1) return -2;               // no ring kernel takes this shape: the caller uses the two-pass form
     g_last_candidate = rc == 1 ? 0 : id;
     return rc == 1 ? launch_legacy(g, st) : rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pdmk_gemm_group: several independent problems in one launch (include/pdmk.h).  A group is launched with ONE kernel shape;
+// which one - or whether the members go out one by one after all - is measured once per group of shapes and cached.
+// ---------------------------------------------------------------------------------------------------------------
+int pdmk_gemm_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st, const long* a_bytes, const long* b_bytes, int id);
+int pdmk_wgrad_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st, const long* a_bytes, const long* b_bytes, int id);
+static int group_mode() { static int c = INT32_MIN; return env_int("PDMK_GEMM_GROUP", 1, &c); }   // 0: always one by one
+static int forced_group() { static int c = INT32_MIN; return env_int("PDMK_GROUP_CFG", -1, &c); } // >= 1: group with that candidate (tests)
+
+namespace {
+
+std::map<std::vector<int>, int> g_group_plan;      // concatenated member keys -> candidate id of the grouped launch, -1 = separate
+
+// planned candidate of one problem (the lookup / tune / heuristic part of pdmk_gemm)
+int member_plan(const pdmk_gemm_args& g, hipStream_t st) {
+    const int sk = g.splitk > 1 ? g.splitk : 1;
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    plan_file_load();
+    const PlanKey key = make_key(g, sk);
+    auto it = g_plan_cfg.find(key);
+    if (it != g_plan_cfg.end()) return it->second;
+    if (!can_tune(st)) return heuristic_cfg(g);
+    float t;
+    int id = tune_cfg(g, st, sk, &t);
+    if (id < 0) id = heuristic_cfg(g);
+    g_plan_cfg[key] = id;
+    plan_file_append('c', key, id);
+    return id;
+}
+
+int group_launch(const pdmk_gemm_args* a, int n, hipStream_t st, int id) {
+    long ab[PDMK_GEMM_GROUP_MAX], bb[PDMK_GEMM_GROUP_MAX];
+    for (int i = 0; i < n; ++i)
+        if (!operand_bytes(a[i], &ab[i], &bb[i])) return 1;
+    if (id <= 0) return 1;
+    if (a[0].a_mode == PDMK_A_COLK) return pdmk_wgrad_ring_group_launch(a, n, st, ab, bb, id - 1);
+    return pdmk_gemm_ring_group_launch(a, n, st, ab, bb, id - 1);
+}
+
+// microseconds per repetition of fn(), best of two rounds of `reps`
+template <typename F> float time_us(F fn, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int reps = 3) {
+    if (fn() != 0) { (void)hipGetLastError(); return 1e30f; }
+    float best = 1e30f;
+    for (int round = 0; round < 2; ++round) {
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps; ++r)
+            if (fn() != 0) { (void)hipGetLastError(); return 1e30f; }
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); return 1e30f; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    return best * 1000.f / reps;
+}
+
+// grouped candidate for these members (ids = their own plans), or -1: launch them one by one.  Caller checked can_tune().
+int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
+    // outputs go to scratch (an accumulating member must not be applied several times)
+    pdmk_gemm_args t[PDMK_GEMM_GROUP_MAX];
+    size_t off[PDMK_GEMM_GROUP_MAX + 1];
+    off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t out = (size_t)a[i].M * (size_t)a[i].N * 4;
+        const size_t slabs = (a[i].accumulate == 2 && a[i].splitk > 1) ? (size_t)a[i].splitk : 1;
+        off[i + 1] = off[i] + ((out * slabs + (size_t)a[i].M * 4 + 1023) & ~(size_t)1023);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!ensure_scratch(off[n] + 256)) return -1;
+    }
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < n; ++i) {
+        t[i] = a[i];
+        char* base = reinterpret_cast<char*>(g_scratch) + off[i];
+        t[i].C = base;
+        t[i].ldc = a[i].N;
+        t[i].C2 = nullptr;
+        if (t[i].accumulate == 1) t[i].accumulate = 0;
+        if (t[i].epilogue == PDMK_EPI_GEGLU) t[i].ldc = a[i].N / 2;
+        if (t[i].colsum_out)
+            t[i].colsum_out = reinterpret_cast<float*>(base + (off[i + 1] - off[i]) - (((size_t)a[i].M * 4 + 15) & ~(size_t)15));
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    const float t_sep = time_us([&]() -> int {
+        for (int i = 0; i < n; ++i) {
+            int rc = launch_candidate(t[i], st, ids[i]);
+            if (rc == 1) rc = launch_legacy(t[i], st);
+            if (rc) return rc;
+        }
+        return 0;
+    }, st, e0, e1);
+    int best = -1;
+    float bt = t_sep * 0.98f;                           // a group must win by > 2 %
+    for (int i = 0; i < n; ++i) {
+        bool seen = ids[i] <= 0;
+        for (int j = 0; j < i; ++j) seen = seen || ids[j] == ids[i];
+        if (seen) continue;
+        const float tg = time_us([&]() -> int { return group_launch(t, n, st, ids[i]); }, st, e0, e1);
+        if (tg < bt) { bt = tg; best = ids[i]; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("PDMK_TUNE_LOG")) {
+        fprintf(stderr, "[pdmk group] n=%d", n);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " (%d,%d,%d|a%d sk%d id%d)", a[i].M, a[i].N, a[i].K, a[i].a_mode, a[i].splitk, ids[i]);
+        fprintf(stderr, " separate %.1f us -> %s %d (%.1f us)\n", t_sep, best > 0 ? "grouped cand" : "separate", best, best > 0 ? bt : t_sep);
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int pdmk_gemm_group(const pdmk_gemm_args* a, int n, pdmk_stream stream, int32_t* grouped_out) {
+    if (grouped_out) *grouped_out = 0;
+    if (!a || n < 1 || n > PDMK_GEMM_GROUP_MAX) return -1;
+    for (int i = 0; i < n; ++i)
+        if (const int vrc = validate_args(a[i])) return vrc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    auto separate = [&]() -> int {
+        for (int i = 0; i < n; ++i)
+            if (const int rc = pdmk_gemm(&a[i], stream)) return rc;
+        return 0;
+    };
+    if (n > 1 && forced_group() >= 1) {                 // tests: this candidate, grouped, no timing
+        const int rc = group_launch(a, n, st, forced_group());
+        if (rc == 0) {
+            g_last_candidate = forced_group();
+            if (grouped_out) *grouped_out = n;
+            return 0;
+        }
+        return rc == 1 ? separate() : rc;
+    }
+    if (n == 1 || !group_mode() || !ring_mode() || forced_cfg() >= 0 || forced_wcfg() >= 0) return separate();
+    bool fw = true, wg = true;
+    for (int i = 0; i < n; ++i) {
+        fw = fw && ring_eligible(a[i]) && (a[i].K % 8) == 0 && (a[i].a_mode == a[0].a_mode);
+        wg = wg && wgrad_eligible(a[i]) && (a[i].b_mode == a[0].b_mode);
+    }
+    if (!fw && !wg) return separate();
+    int ids[PDMK_GEMM_GROUP_MAX];
+    std::vector<int> key;
+    for (int i = 0; i < n; ++i) {
+        ids[i] = member_plan(a[i], st);
+        if (a[i].epilogue && ids[i] <= 0) ids[i] = 1 + pdmk_gemm_ring_pick(a[i]);
+        const PlanKey k = make_key(a[i], a[i].splitk > 1 ? a[i].splitk : 1);
+        key.insert(key.end(), k.v, k.v + 10);
+        key.push_back(a[i].accumulate);
+    }
+    int id = -2;
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        auto it = g_group_plan.find(key);
+        if (it != g_group_plan.end()) id = it->second;
+    }
+    if (id == -2) {
+        if (can_tune(st)) {
+            id = tune_group(a, n, ids, st);
+            std::lock_guard<std::mutex> lk(g_plan_mu);
+            g_group_plan[key] = id;
+        } else {                                          // unseen under capture: group only what needs no decision
+            id = ids[0];
+            for (int i = 1; i < n; ++i)
+                if (ids[i] != ids[0]) id = -1;
+        }
+    }
+    if (id > 0) {
+        const int rc = group_launch(a, n, st, id);
+        if (rc == 0) {
+            g_last_candidate = id;
+            if (grouped_out) *grouped_out = n;
+            return 0;
+        }
+        if (rc != 1) return rc;
+    }
+    return separate();
 }
 
 /* Candidate the calling thread's last pdmk_gemm used (0 = K-step-32 kernels, 1.. = LDS-DMA ring shapes) and the kernel
@@ -902,10 +1089,11 @@ extern "C" int pdmk_plan_clear(void) {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     g_plan_cfg.clear();
     g_plan_sk.clear();
+    g_group_plan.clear();
     if (g_scratch) (void)hipFree(g_scratch);
     g_scratch = nullptr;
     g_scratch_bytes = 0;
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 110; }
+extern "C" int pdmk_version(void) { return 120; }

@@ -28,6 +28,29 @@ struct ConvGeom {
     int hi, wi, ci, ho, wo, ld, mode;
 };
 
+// Launch coordinates of a workgroup inside ITS problem: (tile id, split id, tiles, splits).  A plain launch passes
+// blockIdx / gridDim; a grouped launch (pdmk_gemm_group: up to PDMK_GEMM_GROUP_MAX problems of one kernel shape in one grid)
+// maps the linear workgroup id to (problem, tile, split).  The kernel bodies below are written against LC only.
+struct LC {
+    unsigned bx, by, gx, gy;
+};
+__device__ __forceinline__ LC lc_plain() { return LC{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}; }
+// problem of this workgroup in a grouped launch; false = padding workgroup (every problem starts on a multiple of 8 blocks,
+// so that wgc.bx % 8 - the XCD under round-robin placement - equals the local id % 8 the tile remap assumes)
+__device__ __forceinline__ bool lc_group(const pdmk_gemm_group_dev& gg, int& pi, LC& lc) {
+    const unsigned b = blockIdx.x;
+    pi = 0;
+#pragma unroll
+    for (int i = 1; i < PDMK_GEMM_GROUP_MAX; ++i)
+        if (i < gg.n && b >= (unsigned)gg.start[i]) pi = i;
+    const unsigned local = b - (unsigned)gg.start[pi];
+    const unsigned gx = (unsigned)gg.gx[pi], gy = (unsigned)gg.gy[pi];
+    if (local >= gx * gy) return false;
+    const unsigned z = local / gx;
+    lc = LC{local - z * gx, z, gx, gy};
+    return true;
+}
+
 // source pixel of output pixel (b, oy, ox) under tap (0..8), or -1 (zero padding / zero-insertion hole / tap >= 9)
 __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, int ox, int tap) {
     const int ky = (tap * 11) >> 5;
@@ -49,15 +72,15 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) { pdmk_wait_vmcnt(n); }   
 // TILE2D (halo conv on images wider than a tile): the tile is rows x tw output pixels of an image of width img_w, m0 is
 // its first pixel and local row l is pixel m0 + (l / tw) * img_w + l % tw.
 template <int BM, int NJ, int LDS_BYTES, bool TILE2D = false>
-__device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&acc)[BM / 64][NJ], unsigned char* smem, int m0,
-                                              int n0, int tw = 0, int img_w = 0) {
+__device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC wgc, f32x4 (&acc)[BM / 64][NJ], unsigned char* smem,
+                                              int m0, int n0, int tw = 0, int img_w = 0) {
     auto row_of = [&](int l) { return TILE2D ? m0 + (l / tw) * img_w + (l % tw) : m0 + l; };
     constexpr int BN = 32 * NJ, IM = BM / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
-    const bool first = blockIdx.y == 0;
-    const bool slab = g.accumulate == 2;                 // split-K partials to slab blockIdx.y of a [splitk][M][ldc] workspace
-    const bool atomic = gridDim.y > 1 && !slab;
+    const bool first = wgc.by == 0;
+    const bool slab = g.accumulate == 2;                 // split-K partials to slab wgc.by of a [splitk][M][ldc] workspace
+    const bool atomic = wgc.gy > 1 && !slab;
     const bool acc1 = g.accumulate == 1;
     const bool f32out = g.out_f32 != 0;
     const bool vec8 = ((g.N & 7) == 0) && ((g.ldc & 7) == 0) && (g.R == nullptr || (g.ldr & 7) == 0);
@@ -66,7 +89,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
     constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(64 * SROW * 4 <= LDS_BYTES, "staging image must fit the ring");
-    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)wgc.by * g.M * g.ldc : 0L);
     bf16* Ct = reinterpret_cast<bf16*>(g.C);
     const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
 #pragma unroll
@@ -222,8 +245,11 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, f32x4 (&a
     }
 }
 
+constexpr int ring_smem_bytes(int BM, int NJ, int STAGES) { return STAGES * (BM * 128 + 32 * NJ * 128); }
+
 template <bool CONV, int BM, int NJ, int STAGES, int OCC>
-__global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+__device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigned a_bytes, unsigned b_bytes, const LC wgc,
+                                                unsigned char* smem) {
     typedef Mma<bf16> MM;
     constexpr int BN = 32 * NJ;
     constexpr int IM = BM / 64;                            // 16-row MFMA tiles per wave (waves: 4 in M x 2 in N)
@@ -231,12 +257,12 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
     constexpr int NA = BM / 64;                            // A DMA pieces per wave and stage (8 rows x 128 B each)
     constexpr int NBLK_B = BN / 8, NB = (NBLK_B + 7) / 8;  // B pieces: NBLK_B in all, wave w issues NBLK_B/8 + (w < NBLK_B%8)
     static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+    static_assert(STAGES * SLOT == ring_smem_bytes(BM, NJ, STAGES), "smem size of the kernel wrappers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(wgc.bx, wgc.gx);
     // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
     // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
     // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
@@ -244,8 +270,8 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
     const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int nk_total = (g.K + BK - 1) / BK;
-    const int per = (nk_total + gridDim.y - 1) / gridDim.y;
-    const int kt0 = blockIdx.y * per;
+    const int per = (nk_total + wgc.gy - 1) / wgc.gy;
+    const int kt0 = wgc.by * per;
     const int kt1 = min(nk_total, kt0 + per);
     if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
@@ -368,7 +394,23 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
-    ring_epilogue<BM, NJ, STAGES * SLOT>(g, acc, smem, m0, n0);
+    ring_epilogue<BM, NJ, STAGES * SLOT>(g, wgc, acc, smem, m0, n0);
+}
+
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ring_smem_bytes(BM, NJ, STAGES)];
+    igemm_ring_body<CONV, BM, NJ, STAGES, OCC>(g, a_bytes, b_bytes, lc_plain(), smem);
+}
+// the same body for up to PDMK_GEMM_GROUP_MAX independent problems in one grid (teacher || student layer pairs, the weight
+// gradients of several layers): longer launches, one boundary instead of several
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void igemm_ring_group_kernel(pdmk_gemm_group_dev gg) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[ring_smem_bytes(BM, NJ, STAGES)];
+    int pi;
+    LC wgc;
+    if (!lc_group(gg, pi, wgc)) return;
+    igemm_ring_body<CONV, BM, NJ, STAGES, OCC>(gg.p[pi], gg.a_bytes[pi], gg.b_bytes[pi], wgc, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -382,8 +424,11 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_kernel(pdmk_gemm_args g, u
 // Every loop event issues the same number of DMA instructions per wave (weight tile + one patch piece; surplus pieces
 // re-issue piece 0 = identical bytes, or read out of bounds = zeros into the finished buffer), so the counted
 // s_waitcnt is a constant.
+constexpr int halo_smem_bytes(int NJ, int BSTAGES, int PMAX) { return 2 * PMAX * 128 + BSTAGES * 32 * NJ * 128; }
+
 template <int BM, int NJ, int BSTAGES, int PMAX>
-__global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes, int tw) {
+__device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned a_bytes, unsigned b_bytes, int tw, const LC wgc,
+                                               unsigned char* smem) {
     typedef Mma<bf16> MM;
     constexpr int BN = 32 * NJ, IM = BM / 64;
     constexpr int P_BYTES = PMAX * 128, B_BYTES = BN * 128;
@@ -392,13 +437,13 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     static_assert(PMAX % 8 == 0 && NPW <= 9 - (BSTAGES - 1), "whole pieces; next block's patch issued before its first weight tile");
     static_assert(2 * P_BYTES + BSTAGES * B_BYTES <= 160 * 1024, "LDS");
     static_assert(64 * (BN + 4) * 4 <= 2 * P_BYTES, "epilogue staging fits the patch buffers");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * P_BYTES + BSTAGES * B_BYTES];
+    static_assert(2 * P_BYTES + BSTAGES * B_BYTES == halo_smem_bytes(NJ, BSTAGES, PMAX), "smem size of the kernel wrappers");
     unsigned char* const bring = smem + 2 * P_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(wgc.bx, wgc.gx);
     // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
     // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
     // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
@@ -407,8 +452,8 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int H = g.conv_hi, W = g.conv_wi, Ci = g.conv_ci, HW = H * W;
     const int ncb_total = (Ci + 63) / 64;
-    const int per = (ncb_total + gridDim.y - 1) / gridDim.y;
-    const int cb0 = blockIdx.y * per, cb1 = min(ncb_total, cb0 + per);
+    const int per = (ncb_total + wgc.gy - 1) / wgc.gy;
+    const int cb0 = wgc.by * per, cb1 = min(ncb_total, cb0 + per);
     if (cb0 >= cb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     // tile geometry: rimg rows x tw columns of one image (HW >= BM; tw = W when whole rows fit) or BM/HW whole images
@@ -633,8 +678,22 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
     // must not land on a staged tile, and what __syncthreads() happens to emit is not a contract
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, acc, smem, m0, n0);
-    else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true>(g, acc, smem, mbase, n0, tw, W);
+    if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, wgc, acc, smem, m0, n0);
+    else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true>(g, wgc, acc, smem, mbase, n0, tw, W);
+}
+
+template <int BM, int NJ, int BSTAGES, int PMAX>
+__global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes, int tw) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[halo_smem_bytes(NJ, BSTAGES, PMAX)];
+    conv_halo_body<BM, NJ, BSTAGES, PMAX>(g, a_bytes, b_bytes, tw, lc_plain(), smem);
+}
+template <int BM, int NJ, int BSTAGES, int PMAX>
+__global__ __launch_bounds__(NT, 2) void conv_halo_group_kernel(pdmk_gemm_group_dev gg) {      // aux0 = tile width of the problem
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[halo_smem_bytes(NJ, BSTAGES, PMAX)];
+    int pi;
+    LC wgc;
+    if (!lc_group(gg, pi, wgc)) return;
+    conv_halo_body<BM, NJ, BSTAGES, PMAX>(gg.p[pi], gg.a_bytes[pi], gg.b_bytes[pi], gg.aux0[pi], wgc, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -645,9 +704,11 @@ __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsi
 // column of each DMA lane and to the transposing reads: the 8 k-rows one 32-lane read group touches land in 8 different
 // 32-byte bank groups.  The bias gradient (column sums of dY) is one extra MFMA per A fragment against a ones vector, in
 // the workgroups of the first n-tile only.
+constexpr int wgrad_smem_bytes(int BM, int NJ, int STAGES) { return STAGES * (64 * BM * 2 + 64 * 32 * NJ * 2); }
+
 template <bool CONV, int BM, int NJ, int STAGES, int OCC>
-__global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
-                                                             unsigned b_bytes) {
+__device__ __forceinline__ void wgrad_ring_body(const pdmk_gemm_args& g, int lg_wo, int lg_howo, unsigned a_bytes, unsigned b_bytes,
+                                                const LC wgc, unsigned char* smem) {
     typedef Mma<bf16> MM;
     constexpr int BN = 32 * NJ, IM = BM / 64;
     constexpr int RA = BM * 2, RB = BN * 2;                     // row bytes of the [64 k][BM] / [64 k][BN] tiles: 128 or 256
@@ -656,12 +717,12 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
     static_assert(STAGES >= 2 && STAGES * SLOT * (OCC / 2) <= 160 * 1024, "ring(s) must fit the 160 KiB LDS");
     static_assert(64 * (BN + 4) * 4 <= STAGES * SLOT, "epilogue staging");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+    static_assert(STAGES * SLOT == wgrad_smem_bytes(BM, NJ, STAGES), "smem size of the kernel wrappers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (g.N + BN - 1) / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(wgc.bx, wgc.gx);
     // tile order: the workgroups of one XCD (consecutive logical tiles) share the operand panel that is worth more in its
     // L2 - the A rows (m-major) normally, the weight rows (n-major) for the 8x8-latent forward / dgrad layers, which stream
     // 15-60 MB of weights per launch for 512 output rows (n-major for every N > M measured 3 % slower for the step)
@@ -669,8 +730,8 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
     const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int nk_total = (g.K + BK - 1) / BK;
-    const int per = (nk_total + gridDim.y - 1) / gridDim.y;
-    const int kt0 = blockIdx.y * per;
+    const int per = (nk_total + wgc.gy - 1) / wgc.gy;
+    const int kt0 = wgc.by * per;
     const int kt1 = min(nk_total, kt0 + per);
     if (kt0 >= kt1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
@@ -799,7 +860,22 @@ __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, i
             if (m < g.M) unsafeAtomicAdd(g.colsum_out + m, acs[i][0]);
         }
     }
-    ring_epilogue<BM, NJ, STAGES * SLOT>(g, acc, smem, m0, n0);
+    ring_epilogue<BM, NJ, STAGES * SLOT>(g, wgc, acc, smem, m0, n0);
+}
+
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
+                                                             unsigned b_bytes) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_smem_bytes(BM, NJ, STAGES)];
+    wgrad_ring_body<CONV, BM, NJ, STAGES, OCC>(g, lg_wo, lg_howo, a_bytes, b_bytes, lc_plain(), smem);
+}
+template <bool CONV, int BM, int NJ, int STAGES, int OCC>
+__global__ __launch_bounds__(NT, OCC) void wgrad_ring_group_kernel(pdmk_gemm_group_dev gg) {   // aux0 / aux1 = lg_wo / lg_howo
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_smem_bytes(BM, NJ, STAGES)];
+    int pi;
+    LC wgc;
+    if (!lc_group(gg, pi, wgc)) return;
+    wgrad_ring_body<CONV, BM, NJ, STAGES, OCC>(gg.p[pi], gg.aux0[pi], gg.aux1[pi], gg.a_bytes[pi], gg.b_bytes[pi], wgc, smem);
 }
 
 struct Config {
@@ -947,10 +1023,13 @@ namespace pdmk_ring {
 // read the patch at shifted rows with transposing ds_read_b64_tr_b16 (patch swizzle chunk ^= row & 7: conflict-free
 // for every shift, as in conv_halo_kernel / the attention tiles).  49 KiB of intake per 9.4 MFLOP (192 FLOP/B) against
 // 32 KiB per 2.1 MFLOP (65 FLOP/B) for the 128x128 ring tile.  8 waves = 2 (co halves) x 4 (16-channel ci slices);
-// a wave keeps 2 x 9 accumulator tiles (72 VGPRs).  Pixel blocks are split over gridDim.y; partial tiles are combined
+// a wave keeps 2 x 9 accumulator tiles (72 VGPRs).  Pixel blocks are split over wgc.gy; partial tiles are combined
 // with fp32 atomics in 256-byte rows (plain stores / read-add-store when there is a single split).
+constexpr int wgrad_halo_smem_bytes(int IMW, int STAGES) { return STAGES * (128 * (32 * IMW) * 2 + 288 * 128); }
+
 template <int IMW, int STAGES>      // IMW = 16-row co tiles per wave: 2 (64 co per workgroup) or 4 (128 co)
-__global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+__device__ __forceinline__ void conv_wgrad_halo_body(const pdmk_gemm_args& g, unsigned a_bytes, unsigned b_bytes, const LC wgc,
+                                                     unsigned char* smem) {
     typedef Mma<bf16> MM;
     constexpr int PX = 128, PMAX = 288, BM = 32 * IMW, RA = BM * 2;       // RA = bytes per pixel row of the dY tile
     constexpr int A_BYTES = PX * RA, P_BYTES = PMAX * 128, SLOT = A_BYTES + P_BYTES;
@@ -959,17 +1038,17 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     constexpr int NDMA = PA + NPW;                                    // DMA instructions per wave and stage
     static_assert(STAGES >= 2 && STAGES * SLOT <= 160 * 1024, "LDS");
     static_assert((IMW == 2 || IMW == 4) && BM * 68 * 4 <= STAGES * SLOT, "epilogue staging");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[STAGES * SLOT];
+    static_assert(STAGES * SLOT == wgrad_halo_smem_bytes(IMW, STAGES), "smem size of the kernel wrappers");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 2, wn = wave & 3;
     const int Ci = g.conv_ci, H = g.conv_hi, W = g.conv_wi, HW = H * W;
     const int nct = (Ci + 63) / 64;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(wgc.bx, wgc.gx);
     const int m0 = (tile / nct) * BM, c0 = (tile - (tile / nct) * nct) * 64;
     const int nblk = (g.K + PX - 1) / PX;
-    const int per = (nblk + gridDim.y - 1) / gridDim.y;
-    const int kb0 = blockIdx.y * per, kb1 = min(nblk, kb0 + per);
+    const int per = (nblk + wgc.gy - 1) / wgc.gy;
+    const int kb0 = wgc.by * per, kb1 = min(nblk, kb0 + per);
     if (kb0 >= kb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
 
     const int rimg = HW >= PX ? PX / W : H;                           // rows of an image inside a pixel block
@@ -1124,8 +1203,8 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     // by pdmk_splitk_finish_group); else several splits add with fp32 atomics - ~180 KB per workgroup at ~5 GB/s per CU, which
     // is what bounded this kernel
     const bool slab = g.accumulate == 2;
-    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)blockIdx.y * g.M * g.ldc : 0L);
-    const bool atomic = gridDim.y > 1 && !slab, acc1 = g.accumulate == 1;
+    float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)wgc.by * g.M * g.ldc : 0L);
+    const bool atomic = wgc.gy > 1 && !slab, acc1 = g.accumulate == 1;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
@@ -1149,6 +1228,20 @@ __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g
     }
 }
 
+template <int IMW, int STAGES>
+__global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_halo_smem_bytes(IMW, STAGES)];
+    conv_wgrad_halo_body<IMW, STAGES>(g, a_bytes, b_bytes, lc_plain(), smem);
+}
+template <int IMW, int STAGES>
+__global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_group_kernel(pdmk_gemm_group_dev gg) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_halo_smem_bytes(IMW, STAGES)];
+    int pi;
+    LC wgc;
+    if (!lc_group(gg, pi, wgc)) return;
+    conv_wgrad_halo_body<IMW, STAGES>(gg.p[pi], gg.a_bytes[pi], gg.b_bytes[pi], wgc, smem);
+}
+
 static bool wgrad_halo_ok(const pdmk_gemm_args& g) {
     if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode != PDMK_B_COLK_CONV || !g.out_f32) return false;
     if (g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi || g.alpha != 1.0f) return false;
@@ -1159,6 +1252,89 @@ static bool wgrad_halo_ok(const pdmk_gemm_args& g) {
 }
 
 }  // namespace pdmk_ring
+
+// ---- grouped launches (pdmk_gemm_group): candidate `id` (numbering of pdmk_gemm_ring_launch) for n problems in one grid.
+// Returns 1 when a problem is not served by that candidate (the caller then launches the problems one by one).
+namespace {
+struct GroupGrid {
+    pdmk_gemm_group_dev gg;
+    unsigned total = 0;
+    void add(int i, const pdmk_gemm_args& g, int tiles, int splits, long ab, long bb, int aux0 = 0, int aux1 = 0) {
+        gg.start[i] = (int)total;
+        gg.gx[i] = tiles;
+        gg.gy[i] = splits;
+        gg.a_bytes[i] = (unsigned)ab;
+        gg.b_bytes[i] = (unsigned)bb;
+        gg.aux0[i] = aux0;
+        gg.aux1[i] = aux1;
+        gg.p[i] = g;
+        total += ((unsigned)tiles * (unsigned)splits + 7u) & ~7u;
+    }
+    void finish(int n) {
+        gg.n = n;
+        for (int i = n; i <= PDMK_GEMM_GROUP_MAX; ++i) gg.start[i] = (int)total;
+        for (int i = n; i < PDMK_GEMM_GROUP_MAX; ++i) {
+            gg.gx[i] = gg.gy[i] = 0;
+            gg.a_bytes[i] = gg.b_bytes[i] = 0;
+            gg.aux0[i] = gg.aux1[i] = 0;
+            gg.p[i] = gg.p[0];
+        }
+    }
+};
+}  // namespace
+
+int pdmk_gemm_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st, const long* a_bytes, const long* b_bytes, int id) {
+    using namespace pdmk_ring;
+    if (n < 2 || n > PDMK_GEMM_GROUP_MAX || id < 0) return 1;
+    const bool halo = id >= kNumBase && id < kNumBase + kNumHalo;
+    if (id >= kNumConfigs + kNumHalo) return 1;                       // row-block kernels: not grouped
+    const bool conv = gs[0].a_mode == PDMK_A_CONV;
+    GroupGrid G;
+    for (int i = 0; i < n; ++i) {
+        const pdmk_gemm_args& g = gs[i];
+        if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
+        if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
+        if ((g.a_mode == PDMK_A_CONV) != conv) return 1;              // one template instantiation per launch
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        if (halo) {
+            const int h = id - kNumBase;
+            const int tw = halo_tile_w(g, h, g.splitk);
+            if (tw <= 0) return 1;
+            const int bm = h < 2 ? 256 : 128, bn = 32 * ((h & 1) ? 4 : 5);
+            G.add(i, g, ((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn), sk, a_bytes[i], b_bytes[i], tw);
+        } else {
+            const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
+            const int bn = 32 * c.nj;
+            G.add(i, g, ((g.M + c.bm - 1) / c.bm) * ((g.N + bn - 1) / bn), sk, a_bytes[i], b_bytes[i]);
+        }
+    }
+    G.finish(n);
+    const dim3 grid(G.total);
+    if (halo) {
+        switch (id - kNumBase) {
+            case 0: hipLaunchKernelGGL((conv_halo_group_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, G.gg); break;
+            case 1: hipLaunchKernelGGL((conv_halo_group_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, G.gg); break;
+            case 2: hipLaunchKernelGGL((conv_halo_group_kernel<128, 5, 4, 264>), grid, dim3(NT), 0, st, G.gg); break;
+            default: hipLaunchKernelGGL((conv_halo_group_kernel<128, 4, 5, 264>), grid, dim3(NT), 0, st, G.gg); break;
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
+#define PDMK_RING_GGO(BMv, NJv, STv, OCv)                                                                             \
+    case (BMv * 1000 + NJv * 100 + STv * 10 + OCv):                                                                   \
+        if (conv) hipLaunchKernelGGL((igemm_ring_group_kernel<true, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, G.gg); \
+        else hipLaunchKernelGGL((igemm_ring_group_kernel<false, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, G.gg);   \
+        break;
+    switch (c.bm * 1000 + c.nj * 100 + c.stages * 10 + c.occ) {
+        PDMK_RING_GGO(256, 4, 3, 2) PDMK_RING_GGO(256, 5, 3, 2) PDMK_RING_GGO(128, 4, 4, 2) PDMK_RING_GGO(128, 5, 4, 2)
+        PDMK_RING_GGO(64, 4, 6, 2) PDMK_RING_GGO(64, 5, 5, 2) PDMK_RING_GGO(128, 4, 2, 4) PDMK_RING_GGO(64, 4, 3, 4)
+        PDMK_RING_GGO(64, 5, 2, 4) PDMK_RING_GGO(128, 6, 3, 2) PDMK_RING_GGO(64, 6, 4, 2) PDMK_RING_GGO(128, 5, 2, 4)
+        PDMK_RING_GGO(64, 2, 4, 4) PDMK_RING_GGO(128, 2, 3, 4) PDMK_RING_GGO(64, 3, 4, 4)
+        default: return 1;
+    }
+#undef PDMK_RING_GGO
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
 
 // ---- weight-gradient ring candidates: 128x128 deep / shallow rings, and the smaller tiles whose split-K epilogue moves a
 // quarter to a half of the atomic bytes per workgroup (what bounds the small weights: ~5 GB/s of atomics per CU)
@@ -1214,5 +1390,58 @@ int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes
         default: return 1;
     }
 #undef PDMK_WG_GO
+    return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// grouped weight gradients: candidate `id` (numbering of pdmk_wgrad_ring_launch) for n problems in one grid; 1 = not served
+int pdmk_wgrad_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st, const long* a_bytes, const long* b_bytes, int id) {
+    using namespace pdmk_ring;
+    if (n < 2 || n > PDMK_GEMM_GROUP_MAX || id < 0 || id > kNumW + 1) return 1;
+    const bool conv = gs[0].b_mode == PDMK_B_COLK_CONV;
+    const bool halo = id == kNumW || id == kNumW + 1;
+    GroupGrid G;
+    for (int i = 0; i < n; ++i) {
+        const pdmk_gemm_args& g = gs[i];
+        if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
+        if ((g.b_mode == PDMK_B_COLK_CONV) != conv) return 1;
+        if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
+        if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3)) return 1;
+        const int sk = g.splitk > 1 ? g.splitk : 1;
+        if (halo) {
+            if (!wgrad_halo_ok(g)) return 1;
+            const int nblk = (g.K + 127) / 128, bm = id == kNumW ? 64 : 128;
+            if (sk > nblk) return 1;
+            G.add(i, g, ((g.M + bm - 1) / bm) * ((g.conv_ci + 63) / 64), sk, a_bytes[i], b_bytes[i]);
+        } else {
+            int lg_wo = -1, lg_howo = -1;
+            if (conv) {
+                auto lg = [](int v) { int l = 0; if (v <= 0 || (v & (v - 1))) return -1; while ((1 << l) < v) ++l; return l; };
+                lg_wo = lg(g.conv_wo);
+                lg_howo = lg(g.conv_ho * g.conv_wo);
+                if (lg_wo < 0 || lg_howo < 0) lg_wo = lg_howo = -1;
+            }
+            const WCfg c = kWCfgs[id];
+            const int bn = 32 * c.nj;
+            G.add(i, g, ((g.M + c.bm - 1) / c.bm) * ((g.N + bn - 1) / bn), sk, a_bytes[i], b_bytes[i], lg_wo, lg_howo);
+        }
+    }
+    G.finish(n);
+    const dim3 grid(G.total);
+    if (halo) {
+        if (id == kNumW) hipLaunchKernelGGL((conv_wgrad_halo_group_kernel<2, 3>), grid, dim3(NT), 0, st, G.gg);
+        else hipLaunchKernelGGL((conv_wgrad_halo_group_kernel<4, 2>), grid, dim3(NT), 0, st, G.gg);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
+    const WCfg c = kWCfgs[id];
+#define PDMK_WG_GGO(BMv, NJv, STv, OCv)                                                                               \
+    case (BMv * 1000 + NJv * 100 + STv * 10 + OCv):                                                                   \
+        if (conv) hipLaunchKernelGGL((wgrad_ring_group_kernel<true, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, G.gg); \
+        else hipLaunchKernelGGL((wgrad_ring_group_kernel<false, BMv, NJv, STv, OCv>), grid, dim3(NT), 0, st, G.gg);   \
+        break;
+    switch (c.bm * 1000 + c.nj * 100 + c.stages * 10 + c.occ) {
+        PDMK_WG_GGO(128, 4, 4, 2) PDMK_WG_GGO(128, 4, 2, 4) PDMK_WG_GGO(64, 4, 3, 4) PDMK_WG_GGO(128, 2, 3, 4) PDMK_WG_GGO(64, 2, 4, 4)
+        default: return 1;
+    }
+#undef PDMK_WG_GGO
     return hipGetLastError() == hipSuccess ? 0 : -1000;
 }

@@ -48,6 +48,7 @@ class GemmArgs(C.Structure):
 _SIGS = {
     "pdmk_version": ([], i32),
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
+    "pdmk_gemm_group": ([C.POINTER(GemmArgs), i32, vp, C.POINTER(i32)], i32),
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
     "pdmk_gemm_last_candidate": ([], i32),
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
@@ -144,6 +145,125 @@ def _chk(rc, name):
 
 PROFILE = None   # bench.py sets this to a list: every gemm launch is then bracketed by HIP events on the launch stream
 
+# ---- lockstep recording (teacher || student forward, pdmk_gemm_group): while RECORD is a list every launch wrapper below
+# appends a record instead of launching; run_lockstep() then walks two record lists side by side and issues the launches of
+# both, pairing what the library can serve in one grouped launch.  Host-side work (allocation, planning queries) still
+# happens at record time; records keep their operand tensors alive until they have run.
+RECORD = None
+TAG = ""         # set by the engine before every layer op: records of the same layer op of two models share a tag
+GROUP_MAX = 4
+STATS = {"launches": 0, "grouped": 0}      # launches issued through records since the last reset (tests / bench bookkeeping)
+
+
+class Rec:
+    __slots__ = ("tag", "kind", "fn", "g", "keep", "macs", "meta")
+
+    def __init__(self, kind, fn, g=None, keep=(), macs=None, meta=None):
+        self.tag, self.kind, self.fn, self.g, self.keep, self.macs, self.meta = TAG, kind, fn, g, keep, macs, meta
+
+    def run(self):
+        self.fn()
+
+
+class Recorder:
+    """with Recorder() as r: ...launch wrappers record...;  r.recs is the list."""
+
+    def __enter__(self):
+        global RECORD
+        self.prev, self.recs = RECORD, []
+        RECORD = self.recs
+        return self
+
+    def __exit__(self, *exc):
+        global RECORD
+        RECORD = self.prev
+        return False
+
+
+def _recordable(kind):
+    """Launch wrapper that defers itself while recording (generic: replayed as a closure, never grouped)."""
+    def deco(fn):
+        def wrapped(*a, **kw):
+            if RECORD is not None:
+                RECORD.append(Rec(kind, lambda: fn(*a, **kw)))
+                return None
+            return fn(*a, **kw)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
+def _launch_gemm(g, macs, shape):
+    """pdmk_gemm on a filled argument block (+ the optional HIP-event bracket of bench.py's per-kernel profile)."""
+    if PROFILE is None:
+        _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+    e1.record()
+    kind = ("bf16" if g.dtype == BF16 else "f32", g.a_mode, g.b_mode, _lib.pdmk_gemm_last_candidate())
+    PROFILE.append((kind, 2.0 * (macs if macs is not None else g.M * g.N * g.K), e0, e1, shape))
+
+
+def gemm_group(recs):
+    """Issue the GEMM records `recs` (2..GROUP_MAX independent problems) through pdmk_gemm_group: one launch where the
+    library has a kernel shape for all of them (bit-identical to the separate launches), else one by one."""
+    n = len(recs)
+    arr = (GemmArgs * n)()
+    for i, r in enumerate(recs):
+        arr[i] = r.g
+    got = i32(0)
+    prof = PROFILE is not None
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _chk(_lib.pdmk_gemm_group(arr, n, _st(), C.byref(got)), "pdmk_gemm_group")
+    STATS["launches"] += 1 if got.value == n else n
+    STATS["grouped"] += got.value
+    if prof:
+        e1.record()
+        g0 = recs[0].g
+        kind = ("bf16" if g0.dtype == BF16 else "f32", g0.a_mode, g0.b_mode, _lib.pdmk_gemm_last_candidate(), int(got.value))
+        flops = sum(2.0 * (r.macs if r.macs is not None else r.g.M * r.g.N * r.g.K) for r in recs)
+        PROFILE.append((kind, flops, e0, e1, [(r.g.M, r.g.N, r.g.K, int(r.g.splitk)) for r in recs]))
+    return int(got.value)
+
+
+def run_lockstep(ta, tb, group=True):
+    """Issue two recorded launch sequences (each in its own order) side by side: records of both lists with the same tag and
+    kind go out together - as ONE launch when they are GEMMs the library groups - everything else one by one.  Any
+    interleaving that keeps each list's order is valid (the two sequences are independent)."""
+    last = {}
+    for idx, r in enumerate(ta):
+        last[(r.tag, r.kind)] = idx
+    i = j = 0
+    while i < len(ta) or j < len(tb):
+        if i < len(ta) and j < len(tb) and ta[i].tag == tb[j].tag and ta[i].kind == tb[j].kind:
+            a, b = ta[i], tb[j]
+            i, j = i + 1, j + 1
+            if group and a.kind == "gemm":
+                gemm_group([a, b])
+            elif group and a.kind in _GROUP_FNS:
+                _GROUP_FNS[a.kind]([a, b])
+                STATS["launches"] += 1
+                STATS["grouped"] += 2
+            else:
+                a.run()
+                b.run()
+                STATS["launches"] += 2
+        elif j < len(tb) and (i >= len(ta) or last.get((tb[j].tag, tb[j].kind), -1) < i):
+            tb[j].run()
+            j += 1
+            STATS["launches"] += 1
+        else:
+            ta[i].run()
+            i += 1
+            STATS["launches"] += 1
+
+
+_GROUP_FNS = {}     # kind -> fn(list of Rec): grouped forms of the non-GEMM forward kernels (filled in below)
+
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
@@ -163,15 +283,12 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     g.dtype = dt(A) if dtype is None else dtype
     g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
     g.epilogue, g.C2, g.ldc2 = int(epilogue), _p(C2), int(ldc2)
-    if PROFILE is None:
-        _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
+    shape = (M, N, K, int(splitk))
+    if RECORD is not None:
+        RECORD.append(Rec("gemm", lambda: _launch_gemm(g, macs, shape), g=g, macs=macs,
+                          keep=(A, B, Cout, bias, rowvec, R, colsum_out, C2)))
         return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    _chk(_lib.pdmk_gemm(C.byref(g), _st()), "pdmk_gemm")
-    e1.record()
-    kind = ("bf16" if g.dtype == BF16 else "f32", a_mode, b_mode, _lib.pdmk_gemm_last_candidate())
-    PROFILE.append((kind, 2.0 * (macs if macs is not None else M * N * K), e0, e1, (M, N, K, int(splitk))))
+    _launch_gemm(g, macs, shape)
 
 
 def _ws_bytes(n):
@@ -341,6 +458,7 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
                   accumulate=accumulate)
 
 
+@_recordable("splitk_finish")
 def splitk_finish(ws, Cout, M, N, ldc, nslab, *, bias=None, rowvec=None, R=None, ldr=0, rows_per_b=0, ldrv=0,
                   accumulate=False):
     _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv, nslab,
@@ -400,6 +518,7 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
          accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
 
 
+@_recordable("groupnorm_fwd")
 def groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, Cc, ldx, ldy, G, gs, eps, silu):
     _chk(_lib.pdmk_groupnorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), _p(ws), B, HW, Cc, ldx, ldy, G, gs,
                                  eps, int(silu), dt(x), _st()), "pdmk_groupnorm_fwd")
@@ -468,6 +587,7 @@ def groupnorm_bwd(x, dy, dx, gamma, beta, stats, dgamma, dbeta, ws, B, HW, Cc, l
                                  0 if add is None else add.stride(0), dt(x), _st()), "pdmk_groupnorm_bwd")
 
 
+@_recordable("layernorm_fwd")
 def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
     _chk(_lib.pdmk_layernorm_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), M, Cc, ldx, ldy, eps, dt(x), _st()),
          "pdmk_layernorm_fwd")
@@ -484,6 +604,7 @@ def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx
                                  pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
 
 
+@_recordable("attn_fwd")
 def attn_fwd(q, k, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, scale):
     """qs/ks/vs/os_ = (batch_stride, row_stride) in elements."""
     _chk(_lib.pdmk_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, qs[0], qs[1], ks[0], ks[1], vs[0],
@@ -499,6 +620,7 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, o
          "pdmk_attn_bwd")
 
 
+@_recordable("geglu_fwd")
 def geglu_fwd(x, y, M, Fd, ldx, ldy, layout=0):
     """layout 0: x = [h | g] halves; 1: (h, g) interleaved in blocks of 8 columns (what EPI_GEGLU consumes)."""
     _chk(_lib.pdmk_geglu_fwd(_p(x), _p(y), M, Fd, ldx, ldy, int(layout), dt(x), _st()), "pdmk_geglu_fwd")
@@ -508,11 +630,33 @@ def geglu_bwd(x, dy, dx, M, Fd, ldx, lddy, lddx, layout=0):
     _chk(_lib.pdmk_geglu_bwd(_p(x), _p(dy), _p(dx), M, Fd, ldx, lddy, lddx, int(layout), dt(x), _st()), "pdmk_geglu_bwd")
 
 
+_GEGLU_REFUSED = set()     # (M, N, K) the library has no fused GEGLU kernel for (learnt from eager calls: status -2)
+
+
+def _launch_gemm_geglu(g, macs):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.pdmk_gemm(C.byref(g), _st())
+    if rc == -2:
+        _GEGLU_REFUSED.add((g.M, g.N, g.K))
+        return False
+    _chk(rc, "pdmk_gemm[geglu]")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((("bf16", A_ROWK, B_ROWK, _lib.pdmk_gemm_last_candidate()), 2.0 * (macs if macs is not None else g.M * g.N * g.K),
+                        e0, e1, (g.M, g.N, g.K, 1)))
+    return True
+
+
 def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
     """gl[M, N/2] = GEGLU(A @ B^T + bias) in the GEMM's epilogue, (hidden, gate) columns interleaved in blocks of 8; f (or
     None) receives the [M, N] pre-activation for the backward.  Returns False when the library has no fused kernel for
-    the shape (status -2) - the caller then runs the projection and pdmk_geglu_fwd(layout=1) as two passes."""
-    global PROFILE
+    the shape (status -2) - the caller then runs the projection and pdmk_geglu_fwd(layout=1) as two passes.
+    While recording (lockstep forward) the answer must be known before the launch: shapes a previous eager call was refused
+    for answer False at once, every other shape is recorded as fused (and raises at launch time if the library refuses)."""
+    if (M, N, K) in _GEGLU_REFUSED:
+        return False
     g = GemmArgs()
     g.A, g.B, g.C, g.bias = _p(A), _p(B), _p(gl), _p(bias)
     g.M, g.N, g.K = M, N, K
@@ -520,20 +664,17 @@ def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
     g.a_mode, g.b_mode, g.dtype = A_ROWK, B_ROWK, dt(A)
     g.splitk, g.alpha = 1, 1.0
     g.epilogue, g.C2, g.ldc2 = EPI_GEGLU, _p(f), 0 if f is None else f.stride(0)
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    rc = _lib.pdmk_gemm(C.byref(g), _st())
-    if rc == -2:
-        return False
-    _chk(rc, "pdmk_gemm[geglu]")
-    if PROFILE is not None:
-        e1.record()
-        PROFILE.append((("bf16", A_ROWK, B_ROWK, _lib.pdmk_gemm_last_candidate()), 2.0 * (macs if macs is not None else M * N * K),
-                        e0, e1, (M, N, K, 1)))
-    return True
+    if RECORD is not None:
+        def run():
+            if not _launch_gemm_geglu(g, macs):
+                raise PdmkError(f"fused GEGLU refused for {(M, N, K)} during a recorded (lockstep) forward; run one eager "
+                                f"forward first so that the shape is known")
+        RECORD.append(Rec("gemm", run, g=g, macs=macs, keep=(A, B, gl, f, bias)))
+        return True
+    return _launch_gemm_geglu(g, macs)
 
 
+@_recordable("silu_fwd")
 def silu_fwd(x, y):
     _chk(_lib.pdmk_silu_fwd(_p(x), _p(y), x.numel(), dt(x), _st()), "pdmk_silu_fwd")
 
@@ -542,10 +683,12 @@ def silu_bwd(x, dy, dx):
     _chk(_lib.pdmk_silu_bwd(_p(x), _p(dy), _p(dx), x.numel(), dt(x), _st()), "pdmk_silu_bwd")
 
 
+@_recordable("copy2d")
 def copy2d(src, dst, rows, cols, lds, ldd, accumulate=False):
     _chk(_lib.pdmk_copy2d(_p(src), _p(dst), rows, cols, lds, ldd, int(accumulate), dt(src), _st()), "pdmk_copy2d")
 
 
+@_recordable("cast_permute")
 def cast_permute(src, dst, n0, n1, n2, mode):
     _chk(_lib.pdmk_cast_permute(_p(src), _p(dst), n0, n1, n2, mode, dt(dst), _st()), "pdmk_cast_permute")
 
@@ -554,6 +697,7 @@ def colsum(x, out, rows, N, ld, accumulate=False, nbatch=1, ldo=0):
     _chk(_lib.pdmk_colsum(_p(x), _p(out), rows, N, ld, int(accumulate), nbatch, ldo, dt(x), _st()), "pdmk_colsum")
 
 
+@_recordable("skinny_gemm")
 def skinny_gemm(x, w, y, M, N, K, ldx, ldw, ldy, bias=None, accumulate=False):
     """y[M<=16, N] (+)= x @ w[N, K]^T + bias  (w in the compute dtype; x bf16/fp32; y fp32 or the compute dtype)."""
     _chk(_lib.pdmk_skinny_gemm(_p(x), dt(x), _p(w), _p(y), _p(bias), M, N, K, ldx, ldw, ldy, dt(w),
@@ -569,15 +713,18 @@ def pool2x2_sum(src, dst, B, H, W, Cc):
     _chk(_lib.pdmk_pool2x2_sum(_p(src), _p(dst), B, H, W, Cc, dt(src), _st()), "pdmk_pool2x2_sum")
 
 
+@_recordable("timestep_embed")
 def timestep_embed(t, freqs, out, B, dim):
     _chk(_lib.pdmk_timestep_embed(_p(t), _p(freqs), _p(out), B, dim, dt(out), _st()), "pdmk_timestep_embed")
 
 
+@_recordable("add_noise_velocity")
 def add_noise_velocity(x0, noise, t, sa, sb, noisy, target, B, Cc, HW, cpad):
     _chk(_lib.pdmk_add_noise_velocity(_p(x0), _p(noise), _p(t), _p(sa), _p(sb), _p(noisy), _p(target), B, Cc, HW, cpad,
                                       dt(noisy), _st()), "pdmk_add_noise_velocity")
 
 
+@_recordable("nchw_to_nhwc")
 def nchw_to_nhwc(src, dst, B, Cc, HW, cpad):
     _chk(_lib.pdmk_nchw_to_nhwc(_p(src), _p(dst), B, Cc, HW, cpad, dt(dst), _st()), "pdmk_nchw_to_nhwc")
 

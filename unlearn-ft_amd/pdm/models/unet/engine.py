@@ -159,6 +159,7 @@ class UNetEngine:
         hidden * gelu(gate) [M, N/2], computed in the GEMM's epilogue where the library has the fused kernel (bf16 ring
         kernels; the pre-activation is then only written when a backward pass will need it), else as a second pass."""
         P = self.P
+        k.TAG = key                    # lockstep recording: the same layer op of two models carries the same tag
         e = P.by_key[key + ".weight"]
         Np, Kp = e.shape
         M = x.t.shape[0]
@@ -248,6 +249,7 @@ class UNetEngine:
         rowvec (+ rv_cols = (first column, width)): per-image row added to every pixel = this ResBlock's column slice of
         the batched time-embedding projection [B, sum of widths] (fp32)."""
         P = self.P
+        k.TAG = key
         e = P.by_key[key + ".weight"]
         Cop, _, Cip = e.shape
         assert x.t.shape[1] == Cip, f"{key}: input has {x.t.shape[1]} channels, weight expects {Cip}"
@@ -305,6 +307,7 @@ class UNetEngine:
 
     def groupnorm(self, x, key, B, HW, G, gs, eps, silu):
         P = self.P
+        k.TAG = key
         C = x.t.shape[1]
         y = self._empty(B * HW, C)
         stats = torch.empty((B, G, 2), device=self.dev, dtype=torch.float32)
@@ -323,6 +326,7 @@ class UNetEngine:
 
     def layernorm(self, x, key):
         P = self.P
+        k.TAG = key
         M, C = x.t.shape
         y = self._empty(M, C)
         stats = torch.empty((M, 2), device=self.dev, dtype=torch.float32)
@@ -337,9 +341,10 @@ class UNetEngine:
             self.tape.append(bwd)
         return out
 
-    def attention(self, q, kk, v, B, H, Nq, Nk, q_act, kv_act, q_cols, kv_cols):
+    def attention(self, q, kk, v, B, H, Nq, Nk, q_act, kv_act, q_cols, kv_cols, tag="attn"):
         """q/kk/v: 2-D views [B*N, H*64] (column slices of the projection outputs); *_act own the gradients;
         q_cols / kv_cols = (lo, hi) column ranges of q in q_act and of (k, v) in kv_act."""
+        k.TAG = tag
         d = H * 64
         o = self._empty(B * Nq, d)
         lse = torch.empty((B, H, Nq), device=self.dev, dtype=torch.float32)
@@ -468,13 +473,13 @@ class UNetEngine:
         l1 = self.layernorm(h, t + ".norm1")
         qkv = self.linear(l1, t + ".attn1.to_qkv")
         o = self.attention(qkv.t[:, :d1], qkv.t[:, d1:2 * d1], qkv.t[:, 2 * d1:3 * d1], B, a.h1(), N, N, qkv, qkv,
-                           (0, d1), ((d1, 2 * d1), (2 * d1, 3 * d1)))
+                           (0, d1), ((d1, 2 * d1), (2 * d1, 3 * d1)), tag=t + ".attn1")
         h = self.linear(o, t + ".attn1.to_out.0", bias=t + ".attn1.to_out.0.bias", residual=h)
         l2 = self.layernorm(h, t + ".norm2")
         q = self.linear(l2, t + ".attn2.to_q")
         kv, ko = ehs, self.kv_lay[p][0]      # `ehs` = the batched K/V projection of all transformers; this one's columns
         o = self.attention(q.t[:, :d2], kv.t[:, ko:ko + d2], kv.t[:, ko + d2:ko + 2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
-                           ((ko, ko + d2), (ko + d2, ko + 2 * d2)))
+                           ((ko, ko + d2), (ko + d2, ko + 2 * d2)), tag=t + ".attn2")
         h = self.linear(o, t + ".attn2.to_out.0", bias=t + ".attn2.to_out.0.bias", residual=h)
         l3 = self.layernorm(h, t + ".norm3")
         gl = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True)
@@ -490,6 +495,7 @@ class UNetEngine:
         self.tape = []
         T = ehs.shape[0] // B
         c0 = cfg.block_out_channels[0]
+        k.TAG = "time_embedding"
         te = self._empty(B, c0)
         k.timestep_embed(timesteps, self.freqs, te, B, c0)
         e1 = self.linear(Act(te, rg=False), "time_embedding.linear_1", bias="time_embedding.linear_1.bias")

@@ -275,6 +275,12 @@ class BilevelStepper:
         self.defer_reduce = False
         self.segment_cb = None
         self.in_graph = False          # GraphedBilevel: the pieces run under stream capture, on ONE stream
+        # lockstep forward (PDMK_LOCKSTEP=1; OFF by default): the frozen teacher and the student run the same layer sequence
+        # on independent data (trainer.py:2446-2459, 2951-2954); both forwards are recorded and issued side by side on ONE
+        # stream, layer l of both as one grouped launch where the library has a kernel for the pair (pdmk_gemm_group).
+        # Measured on one MI355X at B = 8 (same-box A/B): 45.8 ms per main step against 42.9 ms with the two
+        # streams - the grouped GEMM launches (121 of them) win less than the two-stream overlap of everything else loses.
+        self.lockstep = os.environ.get("PDMK_LOCKSTEP", "0") == "1" and student.dtype == torch.bfloat16
         self._gscale = 1.0 / world
         # the frozen teacher pass and the student forward are independent until the loss heads: two HIP streams, so that the
         # small-grid layers of one fill the CUs the other leaves idle (PDMK_TEACHER_STREAM=0 runs the teacher in line).
@@ -370,10 +376,11 @@ class BilevelStepper:
         """Teacher cond + uncond predictions of the upper step as ONE batch of 2B (trainer.py:2951-2954)."""
         B, C, H, W = latents.shape
         with phase("fwd_teacher"):
-            noisy, _ = self._diffuse(latents, noise, timesteps, False)
-            ehs2 = torch.cat([self._ehs2d(prompt_embeds), self._ehs2d(empty_prompt_embeds)], 0)
-            noisy2 = torch.cat([noisy, noisy], 0)
+            # (the doubled batch is formed from the INPUTS: nothing here may read the output of a kernel of this pass on the
+            # host side of the stream - under lockstep recording the kernels are issued later)
             t2 = torch.cat([timesteps, timesteps], 0)
+            noisy2, _ = self._diffuse(torch.cat([latents, latents], 0), torch.cat([noise, noise], 0), t2, False)
+            ehs2 = torch.cat([self._ehs2d(prompt_embeds), self._ehs2d(empty_prompt_embeds)], 0)
             return self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
 
     def student_forward(self, latents, noise, timesteps, prompt_embeds, train=True, input_noise=None, want_target=True):
@@ -431,6 +438,17 @@ class BilevelStepper:
     def need_teacher(self):
         return self.w["block"] > 0 or self.w["dist"] > 0
 
+    def forward_pair(self, teacher_fn, student_fn):
+        """Teacher pass and student forward in lockstep on the CURRENT stream: both are recorded (launch wrappers of
+        pdm._pdmk defer themselves), then issued side by side with pdm._pdmk.run_lockstep.  Returns (teacher_out, ctx)."""
+        with k.Recorder() as rt:
+            tout = teacher_fn()
+        with k.Recorder() as rs:
+            ctx = student_fn()
+        with phase("fwd_pair"):
+            k.run_lockstep(rt.recs, rs.recs)
+        return tout, ctx
+
     # ------------------------------------------------------------------ eager steps
     def _beside(self, fn):
         """Runs fn() on the teacher stream beside what the caller queues next; returns (result, join)."""
@@ -452,9 +470,14 @@ class BilevelStepper:
         if backward:
             self.begin_wt_refresh()
         join = lambda: None
-        if teacher_out is None and self.need_teacher:
-            teacher_out, join = self._beside(lambda: self.teacher_pass(latents, noise, timesteps, prompt_embeds, input_noise))
-        ctx = self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, input_noise=input_noise)
+        sfwd = lambda: self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, input_noise=input_noise)
+        if teacher_out is None and self.need_teacher and self.lockstep:
+            teacher_out, ctx = self.forward_pair(
+                lambda: self.teacher_pass(latents, noise, timesteps, prompt_embeds, input_noise), sfwd)
+        else:
+            if teacher_out is None and self.need_teacher:
+                teacher_out, join = self._beside(lambda: self.teacher_pass(latents, noise, timesteps, prompt_embeds, input_noise))
+            ctx = sfwd()
         join()
         self.main_loss_heads(ctx, teacher_out, backward)
         if backward:
@@ -467,9 +490,14 @@ class BilevelStepper:
         predictions computed as ONE batch of 2B."""
         if backward:
             self.begin_wt_refresh()
-        tout, join = self._beside(lambda: self.upper_teacher_pass(latents, noise, timesteps, prompt_embeds, empty_prompt_embeds))
-        ctx = self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, want_target=False)
-        join()
+        tfwd = lambda: self.upper_teacher_pass(latents, noise, timesteps, prompt_embeds, empty_prompt_embeds)
+        sfwd = lambda: self.student_forward(latents, noise, timesteps, prompt_embeds, train=backward, want_target=False)
+        if self.lockstep:
+            tout, ctx = self.forward_pair(tfwd, sfwd)
+        else:
+            tout, join = self._beside(tfwd)
+            ctx = sfwd()
+            join()
         self.upper_loss_heads(ctx, tout, backward)
         if backward:
             with phase("bwd"):
@@ -614,15 +642,20 @@ class GraphedBilevel:
         try:
             with torch.cuda.stream(cap):
                 tout = None
-                if need_t:
+                tfwd = ((lambda: st.upper_teacher_pass(self.lat, self.noise, self.t, self.ehs, self.empty)) if upper else
+                        (lambda: st.teacher_pass(self.lat, self.noise, self.t, self.ehs)))
+                sfwd = lambda: st.student_forward(self.lat, self.noise, self.t, self.ehs, train=True, want_target=not upper)
+                if need_t and not st.lockstep:             # teacher as its own graph, replayed on the teacher stream
                     cs.teacher = torch.cuda.CUDAGraph()
                     cs.teacher.capture_begin(capture_error_mode="thread_local")
-                    tout = (st.upper_teacher_pass(self.lat, self.noise, self.t, self.ehs, self.empty) if upper else
-                            st.teacher_pass(self.lat, self.noise, self.t, self.ehs))
+                    tout = tfwd()
                     cs.teacher.capture_end()
                 cs.fwd = torch.cuda.CUDAGraph()
                 cs.fwd.capture_begin(capture_error_mode="thread_local")
-                ctx = st.student_forward(self.lat, self.noise, self.t, self.ehs, train=True, want_target=not upper)
+                if need_t and st.lockstep:                 # teacher || student in lockstep inside ONE graph
+                    tout, ctx = st.forward_pair(tfwd, sfwd)
+                else:
+                    ctx = sfwd()
                 cs.fwd.capture_end()
                 cs.bwd.append(torch.cuda.CUDAGraph())
                 cs.bwd[-1].capture_begin(pool=cs.fwd.pool(), capture_error_mode="thread_local")
