@@ -110,6 +110,23 @@ int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
  * K-step-32 / row-block plans) and groups that measured slower than their separate launches are launched one by one.  The first time a group of shapes is
  * seen outside stream capture the library times {grouped with each member's planned shape, separate} and caches the choice.
  * *grouped_out (optional): number of problems that went out in a multi-problem launch. */
+/* conv_mode 5..12 (A_CONV; 5..8 also B_COLK_CONV): nearest-x2 upsample + 3x3 conv (Upsample2D of the up blocks,
+ * pdm/models/unet/unet_2d_conditional.py:1691-1706 via (D) Upsample2D) as FOUR 2x2 convs on the
+ * low-resolution image: output pixel (2y + a, 2x + b') reads source rows y - 1 + a .. y + a with the 3x3 taps that fall on
+ * the same source pixel summed (pdmk_up2_pack_weights) - 16 instead of 36 multiply-accumulates per low-resolution pixel, the
+ * same arithmetic up to the rounding of the summed weights.  The GEMM enumerates the hi x wi low-resolution grid (conv_ho =
+ * conv_hi, conv_wo = conv_wi, M or K = conv_b * hi * wi), K (N for the weight gradient) = 4 * conv_ci, phase p = 2a + b':
+ *   5 + p  forward of phase p: A = the low-resolution image, row m is STORED at pixel (b, 2y + a, 2x + b') of the 2hi x 2wi
+ *          output C; as B_COLK_CONV: weight gradient of phase p (A = dY of the 2hi x 2wi image, rows gathered the same way);
+ *   9 + p  input gradient through phase p: A = the 2hi x 2wi gradient read at (b, 2y + a, 2x + b'), B = wpt of the phase,
+ *          C = the low-resolution gradient (the four phases accumulate).
+ * bf16, LDS-DMA halo kernels (128-row tiles) / ring weight-gradient kernels only: -2 where they do not take the shape
+ * (pdmk_conv_up2_supported answers beforehand; the caller then uses conv_mode 2). */
+int pdmk_conv_up2_supported(int B, int H, int W, int Ci, int Co, int dtype);
+/* w3 [Co][9][Ci] fp32 (the packed 3x3 master weight) -> wp [4][Co][4][Ci] and (optional) wpt [4][Ci][4][Co] in `dtype`;
+ * dw3 [Co][9][Ci] += the four phase gradients dwp [4][Co][4][Ci] (fp32). */
+int pdmk_up2_pack_weights(const float* w3, void* wp, void* wpt, int Co, int Ci, int dtype, pdmk_stream stream);
+int pdmk_up2_combine_wgrad(const float* dwp, float* dw3, int Co, int Ci, pdmk_stream stream);
 #define PDMK_GEMM_GROUP_MAX 4
 int pdmk_gemm_group(const pdmk_gemm_args* args, int n, pdmk_stream stream, int32_t* grouped_out);
 /* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller

@@ -1033,3 +1033,66 @@ def test_gemm_group_wgrad_matches_separate(dev, force_cfg, cand):
     else:
         ref = dy.float().t() @ x.float()
     close(got0, ref, 2e-2, "group wgrad vs fp32")
+
+
+@pytest.mark.parametrize("B,H,Ci,Co", [(2, 8, 64, 160), (2, 16, 96, 64), (1, 32, 32, 320), (3, 8, 160, 128)])
+def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
+    """Upsample2D = nearest x2 + 3x3 conv as four 2x2 phase convs on the low-resolution image
+    (conv_mode 5..12, pdmk_up2_pack_weights / pdmk_up2_combine_wgrad): forward (one grouped launch of the four phases),
+    input gradient and weight / bias gradient against F.interpolate + F.conv2d autograd in fp32 on the bf16-rounded
+    operands.  Summing the 3x3 taps before the bf16 rounding is the only arithmetic difference: bf16 tolerance."""
+    from pdm import _pdmk as k
+    torch.manual_seed(B * 100 + H + Ci)
+    dt = torch.bfloat16
+    W = H
+    assert k.conv_up2_supported(B, H, W, Ci, Co, dt)
+    x = rnd((B * H * W, Ci), dev, dt)
+    w3 = rnd((Co, 9 * Ci), dev, torch.float32, 0.05)            # packed [Co][9][Ci] fp32 master
+    bias = rnd((Co,), dev, torch.float32)
+    wp = torch.empty(4, Co, 4 * Ci, device=dev, dtype=dt)
+    wpt = torch.empty(4, Ci, 4 * Co, device=dev, dtype=dt)
+    k.up2_pack_weights(w3, wp, wpt, Co, Ci)
+    geo = lambda m, ci, ld: (B, H, W, ci, H, W, m, ld)
+    Ml, Mh = B * H * W, B * 4 * H * W
+    y = torch.zeros(Mh, Co, device=dev, dtype=dt)
+    with k.Recorder() as r:
+        for p in range(4):
+            k.gemm(x, wp[p], y, Ml, Co, 4 * Ci, 0, 4 * Ci, Co, a_mode=k.A_CONV, conv=geo(5 + p, Ci, Ci), bias=bias)
+    k.gemm_group(r.recs)
+    # reference: autograd on fp32 copies of the bf16 operands (weights: the fp32 master, as the 3x3 form would round them)
+    xr = x.float().view(B, H, W, Ci).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w3.view(Co, 3, 3, Ci).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    yr = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
+    close(y.float(), yr.permute(0, 2, 3, 1).reshape(Mh, Co), 2e-2, "up2 forward")
+    dy = rnd((Mh, Co), dev, dt)
+    yr.backward(dy.float().view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2))
+    # input gradient: the four phases accumulate
+    dx = torch.zeros(Ml, Ci, device=dev, dtype=dt)
+    for p in range(4):
+        k.gemm(dy, wpt[p], dx, Ml, Ci, 4 * Co, 0, 4 * Co, Ci, a_mode=k.A_CONV, conv=geo(9 + p, Co, Co), accumulate=p > 0)
+    close(dx.float(), xr.grad.permute(0, 2, 3, 1).reshape(Ml, Ci), 3e-2, "up2 dgrad")
+    # weight / bias gradient
+    dwp = torch.zeros(4, Co, 4 * Ci, device=dev)
+    db = torch.zeros(Co, device=dev)
+    sk = k.wgrad_plan(dy, x, Co, 4 * Ci, Ml, Co, 0, k.B_COLK_CONV, geo(5, Ci, Ci))
+    with k.Recorder() as rw:
+        for p in range(4):
+            k.gemm(dy, x, dwp[p], Co, 4 * Ci, Ml, Co, 0, 4 * Ci, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV, conv=geo(5 + p, Ci, Ci),
+                   out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.BF16, colsum_out=db)
+    k.gemm_group(rw.recs)
+    dw3 = torch.zeros(Co, 9 * Ci, device=dev)
+    k.up2_combine_wgrad(dwp, dw3, Co, Ci)
+    close(dw3, wr.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci), 2e-2, "up2 wgrad")
+    close(db, br.grad, 2e-2, "up2 bias grad")
+    # the packed phase weights are exact sums of the 3x3 taps (fp32 master -> one rounding)
+    w9 = w3.view(Co, 3, 3, Ci)
+    S = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    for p in range(4):
+        a, b = p >> 1, p & 1
+        for dy_ in range(2):
+            for dx_ in range(2):
+                ref = sum(w9[:, ky, kx] for ky in S[(a, dy_)] for kx in S[(b, dx_)])
+                got = wp[p].view(Co, 2, 2, Ci)[:, dy_, dx_]
+                assert torch.equal(got, ref.to(dt)), (p, dy_, dx_)
+                assert torch.equal(wpt[p].view(Ci, 2, 2, Co)[:, 1 - dy_, 1 - dx_], got.t())

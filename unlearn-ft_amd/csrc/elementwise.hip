@@ -503,6 +503,48 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ upsampling conv as 4 phases
+// nearest-x2 upsample + 3x3 conv == four 2x2 convs on the low-resolution image (conv_mode 5..12, gemm_ring.hip): the 3x3 taps
+// that fall on the same source pixel are summed.  For output phase a (row parity) source row offset dy in {0, 1} collects
+// ky in S(a, dy): S(0,0) = {0}, S(0,1) = {1, 2}, S(1,0) = {0, 1}, S(1,1) = {2}; likewise for columns.
+__device__ __forceinline__ int up2_lo(int a, int d) { return a == 0 ? (d == 0 ? 0 : 1) : (d == 0 ? 0 : 2); }
+__device__ __forceinline__ int up2_hi(int a, int d) { return a == 0 ? (d == 0 ? 0 : 2) : (d == 0 ? 1 : 2); }
+__device__ __forceinline__ int up2_d(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k <= 1 ? 0 : 1); }   // dy of tap ky under phase a
+
+// w3 [Co][9][Ci] fp32 master -> wp [4][Co][4][Ci] (forward) and wpt [4][Ci][4][Co] (input gradient of phase p:
+// wpt[p][ci][(e, f)][co] = wp[p][co][(1 - e, 1 - f)][ci]), both in T; the sums are formed in fp32 and rounded once
+template <typename T>
+__global__ void up2_pack_kernel(const float* __restrict__ w3, T* __restrict__ wp, T* __restrict__ wpt, int Co, int Ci) {
+    const long total = 4L * Co * 4 * Ci;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int ci = (int)(i % Ci);
+        long r = i / Ci;
+        const int j = (int)(r & 3);
+        r >>= 2;
+        const int co = (int)(r % Co), p = (int)(r / Co);
+        const int a = p >> 1, b = p & 1, dy = j >> 1, dx = j & 1;
+        float s = 0.f;
+        for (int ky = up2_lo(a, dy); ky <= up2_hi(a, dy); ++ky)
+            for (int kx = up2_lo(b, dx); kx <= up2_hi(b, dx); ++kx) s += w3[((long)co * 9 + ky * 3 + kx) * Ci + ci];
+        wp[i] = from_f32<T>(s);
+        if (wpt) wpt[(((long)p * Ci + ci) * 4 + ((1 - dy) * 2 + (1 - dx))) * Co + co] = from_f32<T>(s);
+    }
+}
+// dw3 [Co][9][Ci] += the phase gradients dwp [4][Co][4][Ci]: tap (ky, kx) belongs to exactly one (dy, dx) of every phase
+__global__ void up2_combine_kernel(const float* __restrict__ dwp, float* __restrict__ dw3, int Co, int Ci) {
+    const long total = (long)Co * 9 * Ci;
+    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int ci = (int)(i % Ci);
+        const long r = i / Ci;
+        const int t = (int)(r % 9), co = (int)(r / 9), ky = t / 3, kx = t - 3 * ky;
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            s += dwp[(((long)p * Co + co) * 4 + (up2_d(p >> 1, ky) * 2 + up2_d(p & 1, kx))) * Ci + ci];
+        dw3[i] += s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ AdamW / sumsq
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, const float* __restrict__ lrp, float b1, float b2, float eps, float wd,
@@ -768,6 +810,23 @@ extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, c
         hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
                            (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate);
     else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_up2_pack_weights(const float* w3, void* wp, void* wpt, int Co, int Ci, int dtype, pdmk_stream s) {
+    if (!w3 || !wp || Co <= 0 || Ci <= 0) return -1;
+    const dim3 grid(grid_for(4L * Co * 4 * Ci, 4096));
+    if (dtype == PDMK_BF16)
+        hipLaunchKernelGGL(up2_pack_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, w3, (bf16*)wp, (bf16*)wpt, Co, Ci);
+    else if (dtype == PDMK_F32)
+        hipLaunchKernelGGL(up2_pack_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, w3, (float*)wp, (float*)wpt, Co, Ci);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_up2_combine_wgrad(const float* dwp, float* dw3, int Co, int Ci, pdmk_stream s) {
+    if (!dwp || !dw3 || Co <= 0 || Ci <= 0) return -1;
+    hipLaunchKernelGGL(up2_combine_kernel, dim3(grid_for((long)Co * 9 * Ci, 4096)), dim3(NT), 0, (hipStream_t)s, dwp, dw3, Co, Ci);
     PDMK_CHECK_LAUNCH();
     return 0;
 }

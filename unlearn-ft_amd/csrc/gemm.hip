@@ -578,19 +578,24 @@ bool ring_eligible(const pdmk_gemm_args& g) {
 
 bool wgrad_eligible(const pdmk_gemm_args& g) {
     return g.dtype == PDMK_BF16 && g.a_mode == PDMK_A_COLK && g.b_mode != PDMK_B_ROWK && g.out_f32 &&
-           (g.b_mode == PDMK_B_COLK || g.conv_mode <= 2);
+           (g.b_mode == PDMK_B_COLK || g.conv_mode <= 2 || (g.conv_mode >= 5 && g.conv_mode <= 8));
 }
 
 bool operand_bytes(const pdmk_gemm_args& g, long* ab, long* bb) {
-    const long conv_bytes = (((long)g.conv_b * g.conv_hi * g.conv_wi - 1) * g.conv_ld + g.conv_ci) * 2;
+    // phase modes: the gradient phases (9..12) read a 2hi x 2wi image; the weight gradient of a phase (5..8) reads dY rows of
+    // the 2hi x 2wi image
+    const long in_px = (long)g.conv_b * g.conv_hi * g.conv_wi * ((g.a_mode == PDMK_A_CONV && g.conv_mode >= 9) ? 4 : 1);
+    const long conv_bytes = ((in_px - 1) * g.conv_ld + g.conv_ci) * 2;
+    const long krows = (g.a_mode == PDMK_A_COLK && g.b_mode == PDMK_B_COLK_CONV && g.conv_mode >= 5) ? 4L * g.K : (long)g.K;
     *ab = g.a_mode == PDMK_A_ROWK ? ((long)(g.M - 1) * g.lda + g.K) * 2
-        : g.a_mode == PDMK_A_CONV ? conv_bytes : ((long)(g.K - 1) * g.lda + g.M) * 2;
+        : g.a_mode == PDMK_A_CONV ? conv_bytes : ((krows - 1) * g.lda + g.M) * 2;
     *bb = g.b_mode == PDMK_B_ROWK ? ((long)(g.N - 1) * g.ldb + g.K) * 2
         : g.b_mode == PDMK_B_COLK ? ((long)(g.K - 1) * g.ldb + g.N) * 2 : conv_bytes;
     return *ab < (1L << 31) && *bb < (1L << 31);
 }
 
 int launch_legacy(const pdmk_gemm_args& g, hipStream_t st) {
+    if ((g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) && g.conv_mode >= 5) return -2;   // phase convs: LDS-DMA kernels only
     const long nblocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.splitk > 1 ? g.splitk : 1);
     long ab, bb;
     if (dma_mode() && (nblocks >= 384 || dma_mode() == 2) && ring_eligible(g) && (g.K % 32) == 0 && operand_bytes(g, &ab, &bb)) {
@@ -696,7 +701,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
 
 int heuristic_cfg(const pdmk_gemm_args& g) {
     if (!ring_mode()) return 0;
-    if (g.a_mode == PDMK_A_COLK) return g.b_mode == PDMK_B_COLK_CONV ? 2 : 0;   // what the tuned plans pick most often
+    if (g.a_mode == PDMK_A_COLK) return (g.b_mode == PDMK_B_COLK_CONV || g.conv_mode >= 5) ? 2 : 0;   // what the tuned plans pick most often
     return 1 + pdmk_gemm_ring_pick(g);
 }
 
@@ -739,14 +744,20 @@ static int validate_args(const pdmk_gemm_args& g) {
     if (g.b_mode == PDMK_B_ROWK && (g.ldb % ch)) return -1;
     if (g.b_mode == PDMK_B_COLK && ((g.ldb % ch) || (g.N % g4))) return -1;
     if (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) {
-        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 4) return -1;
+        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 12) return -1;
+        if (g.conv_mode >= 5) {     // 2x2 phase of a nearest-x2 upsample + 3x3 conv (pdmk.h): bf16 LDS-DMA kernels only
+            if (g.dtype != PDMK_BF16 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return -2;
+            if (g.b_mode == PDMK_B_COLK_CONV && g.conv_mode > 8) return -1;
+        }
         if (g.conv_mode == 4 && (g.b_mode == PDMK_B_COLK_CONV || (g.conv_hi & 1) || (g.conv_wi & 1))) return -1;   // forward only
         if (g.conv_b <= 0 || g.conv_hi <= 0 || g.conv_wi <= 0 || g.conv_ho <= 0 || g.conv_wo <= 0) return -1;
         const long px = (long)g.conv_b * g.conv_ho * g.conv_wo;
         if (px >= (1L << 30) || (long)g.conv_b * g.conv_hi * g.conv_wi >= (1L << 30)) return -1;   // 32-bit pixel ids
-        if (g.a_mode == PDMK_A_CONV && (g.M != px || g.K != 9 * g.conv_ci)) return -1;
-        if (g.b_mode == PDMK_B_COLK_CONV && (g.K != px || g.N != 9 * g.conv_ci)) return -1;
+        const int ntaps = g.conv_mode >= 5 ? 4 : 9;
+        if (g.a_mode == PDMK_A_CONV && (g.M != px || g.K != ntaps * g.conv_ci)) return -1;
+        if (g.b_mode == PDMK_B_COLK_CONV && (g.K != px || g.N != ntaps * g.conv_ci)) return -1;
         // gather geometry must be consistent with the source extent (out-of-image taps read as zero padding)
+        if (g.conv_mode >= 5 && (long)g.conv_b * g.conv_hi * g.conv_wi * 4 >= (1L << 30)) return -1;
         const bool half = g.conv_mode == 1 || g.conv_mode == 4, twice = g.conv_mode == 2 || g.conv_mode == 3;
         const int eh = half ? (g.conv_hi + 1) / 2 : (twice ? 2 * g.conv_hi : g.conv_hi);
         const int ew = half ? (g.conv_wi + 1) / 2 : (twice ? 2 * g.conv_wi : g.conv_wi);

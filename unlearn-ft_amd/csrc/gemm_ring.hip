@@ -53,6 +53,11 @@ __device__ __forceinline__ bool lc_group(const pdmk_gemm_group_dev& gg, int& pi,
 
 // source pixel of output pixel (b, oy, ox) under tap (0..8), or -1 (zero padding / zero-insertion hole / tap >= 9)
 __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, int ox, int tap) {
+    if (g.mode >= 5) {            // 2x2 phase (a, b') of an upsampling conv: tap (dy, dx) reads pixel (oy + dy - 1 + a, ox + dx - 1 + b')
+        const int ph = g.mode - 5, vy = oy + (tap >> 1) - 1 + (ph >> 1), vx = ox + (tap & 1) - 1 + (ph & 1);
+        const bool ok = (unsigned)vy < (unsigned)g.hi && (unsigned)vx < (unsigned)g.wi && tap < 4;
+        return ok ? (b * g.hi + vy) * g.wi + vx : -1;
+    }
     const int ky = (tap * 11) >> 5;
     const int kx = tap - 3 * ky;
     const bool s2 = g.mode == 1 || g.mode == 4, up = g.mode == 2 || g.mode == 3;
@@ -71,10 +76,18 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) { pdmk_wait_vmcnt(n); }   
 // 16-byte rows of C with bias / rowvec / residual / accumulate fused, or fp32 atomics for split-K launches.
 // TILE2D (halo conv on images wider than a tile): the tile is rows x tw output pixels of an image of width img_w, m0 is
 // its first pixel and local row l is pixel m0 + (l / tw) * img_w + l % tw.
-template <int BM, int NJ, int LDS_BYTES, bool TILE2D = false>
+// OUTMAP (2x2 phase of an upsampling conv, conv_mode 5..8): row m is pixel (b, y, x) of the hi x wi grid the GEMM enumerates
+// and is STORED at pixel (b, 2y + oa, 2x + ob) of the 2hi x 2wi output image (bounds, bias and rowvec still go by m).
+template <int BM, int NJ, int LDS_BYTES, bool TILE2D = false, bool OUTMAP = false>
 __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC wgc, f32x4 (&acc)[BM / 64][NJ], unsigned char* smem,
                                               int m0, int n0, int tw = 0, int img_w = 0) {
     auto row_of = [&](int l) { return TILE2D ? m0 + (l / tw) * img_w + (l % tw) : m0 + l; };
+    auto out_row = [&](int m) -> long {
+        if (!OUTMAP) return (long)m;
+        const int hw = g.conv_hi * g.conv_wi, b = m / hw, rem = m - b * hw, y = rem / g.conv_wi, x = rem - y * g.conv_wi;
+        const int ph = g.conv_mode - 5;
+        return ((long)(b * 2 * g.conv_hi + 2 * y + (ph >> 1)) * (2 * g.conv_wi) + 2 * x + (ph & 1));
+    };
     constexpr int BN = 32 * NJ, IM = BM / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-dependent branches and counts stay in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
@@ -173,7 +186,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
                 const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
                 const bool ok = item < 64 * C8 && m < g.M && n < g.N;
-                const long off = (long)m * g.ldc + n;
+                const long off = out_row(m) * g.ldc + n;
                 if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
                 if (ok && acc1 && !f32out) cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
             }
@@ -202,7 +215,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)rres[it][r];
                 }
-                const long off = (long)m * g.ldc + n;
+                const long off = out_row(m) * g.ldc + n;
                 if (f32out) {
                     float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
                     if (acc1) {       // fp32 accumulate (weight gradients without split-K): read in place
@@ -230,7 +243,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
                 const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
                 if (m >= g.M || n >= g.N) continue;
                 const float* rv = g.rowvec ? g.rowvec + (long)(m / g.rows_per_b) * (g.ldrv ? g.ldrv : g.N) : nullptr;
-                const long off = (long)m * g.ldc + n;
+                const long off = out_row(m) * g.ldc + n;
                 const int nv = min(8, g.N - n);
                 for (int r = 0; r < nv; ++r) {
                     float x = stage[lr2 * SROW + c8 * 8 + r];
@@ -426,7 +439,13 @@ __global__ __launch_bounds__(NT, OCC) void igemm_ring_group_kernel(pdmk_gemm_gro
 // s_waitcnt is a constant.
 constexpr int halo_smem_bytes(int NJ, int BSTAGES, int PMAX) { return 2 * PMAX * 128 + BSTAGES * 32 * NJ * 128; }
 
-template <int BM, int NJ, int BSTAGES, int PMAX>
+// NTAPS = 4: one 2x2 PHASE of a nearest-x2 upsample + 3x3 conv (conv_mode 5..12).  An output pixel (2y + a, 2x + b') of the
+// upsampled conv reads a 2x2 neighbourhood of the LOW-resolution image with weights that are sums of the 3x3 taps falling on
+// the same source pixel: 16 instead of 36 multiply-accumulates per low-resolution pixel.  In this kernel a phase is the 3x3
+// conv restricted to the taps (a + dy, b' + dx), dy, dx in {0, 1}, of the SAME halo patch; modes 5..8 (forward) store row
+// (b, y, x) at pixel (b, 2y + a, 2x + b') of the 2H x 2W output, modes 9..12 (input gradient) READ pixel (b, 2y + a, 2x + b')
+// of the 2H x 2W gradient as pixel (b, y, x) and use the taps of phase (1 - a, 1 - b').  Two-taps-per-barrier path only.
+template <int BM, int NJ, int BSTAGES, int PMAX, int NTAPS = 9>
 __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned a_bytes, unsigned b_bytes, int tw, const LC wgc,
                                                unsigned char* smem) {
     typedef Mma<bf16> MM;
@@ -434,7 +453,13 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     constexpr int P_BYTES = PMAX * 128, B_BYTES = BN * 128;
     constexpr int NBLK_B = BN / 8, NB = (NBLK_B + 7) / 8;
     constexpr int NPW = (PMAX / 8 + 7) / 8;                          // patch pieces per wave (max)
-    static_assert(PMAX % 8 == 0 && NPW <= 9 - (BSTAGES - 1), "whole pieces; next block's patch issued before its first weight tile");
+    static_assert(PMAX % 8 == 0 && (NTAPS == 4 || NPW <= 9 - (BSTAGES - 1)), "whole pieces; next block's patch issued before its first weight tile");
+    static_assert(NTAPS == 9 || (NTAPS == 4 && BSTAGES >= 4 && PDMK_HALO_PAIRS), "phase convs run the two-taps-per-barrier path");
+    // phase geometry (NTAPS == 4): tap phase (ta, tb); strided input (in_s = 2, offsets ia, ib) for the gradient modes
+    const int phm = NTAPS == 4 ? g.conv_mode - 5 : 0;
+    const bool dgr = NTAPS == 4 && phm >= 4;
+    const int pa_ = (phm & 3) >> 1, pb_ = phm & 1;
+    const int ta = dgr ? 1 - pa_ : pa_, tb = dgr ? 1 - pb_ : pb_;
     static_assert(2 * P_BYTES + BSTAGES * B_BYTES <= 160 * 1024, "LDS");
     static_assert(64 * (BN + 4) * 4 <= 2 * P_BYTES, "epilogue staging fits the patch buffers");
     static_assert(2 * P_BYTES + BSTAGES * B_BYTES == halo_smem_bytes(NJ, BSTAGES, PMAX), "smem size of the kernel wrappers");
@@ -490,7 +515,8 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
             const int py = rem / W2, px = rem - py * W2;
             const int b = img0 + il, y = y0 + py - 1, x = x0 + px - 1;
             if (b < g.conv_b && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                poff[j] = (unsigned)((b * H + y) * W + x) * (unsigned)g.conv_ld * 2u;
+                poff[j] = (dgr ? (unsigned)((b * 2 * H + 2 * y + pa_) * (2 * W) + 2 * x + pb_)
+                               : (unsigned)((b * H + y) * W + x)) * (unsigned)g.conv_ld * 2u;
         }
     }
     // ---- weight loader (as in the ring kernel)
@@ -544,7 +570,7 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
 
     // one tap: 2 x (IM x NJ) MFMAs out of the patch (shifted rows) and one weight tile
     auto tap_compute = [&](const unsigned char* pbuf, const unsigned char* sb, int tap) __attribute__((always_inline)) {
-        const int toff = (tap / 3) * W2 + (tap % 3);
+        const int toff = NTAPS == 4 ? (ta + (tap >> 1)) * W2 + (tb + (tap & 1)) : (tap / 3) * W2 + (tap % 3);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[IM], bf[NJ];
@@ -564,7 +590,7 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
         __builtin_amdgcn_sched_barrier(0);            // no cross-tap code motion: keeps fragment live ranges to one tap
     };
 
-    const int nsteps = cb1 > cb0 ? (cb1 - cb0) * 9 : 0;
+    const int nsteps = cb1 > cb0 ? (cb1 - cb0) * NTAPS : 0;
     if (BSTAGES >= 4 && PDMK_HALO_PAIRS) {
         // ---- two taps per barrier (rings of >= 4 slots: the 128-row tiles).  A K-step of an 8-wave workgroup has ~480 cycles
         // of fixed cost (wait + barrier rendezvous + restart of the MFMA stream) next to 640 cycles of MFMA work
@@ -581,15 +607,18 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
         issue_b(nsteps > 0 ? cb0 : cb1, 0, 0);
         issue_b(nsteps > 0 ? cb0 : cb1, 1, 1);
         int slot_c = 0;
+        constexpr int NE = (NTAPS + 1) / 2;                       // events per channel block: (0,1)(2,3)(4,5)(6,7)(8) / (0,1)(2,3)
+        constexpr int PPT = NTAPS == 9 ? 1 : (NPW + NTAPS - 1) / NTAPS;
         for (int cb = cb0; cb < cb1; ++cb) {
             const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
 #pragma unroll
             for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
-                const int t0 = 2 * e, ne = e < 4 ? 2 : 1;                 // this event's taps
-                const int nn = e == 3 ? 1 : 2;                            // taps of the NEXT event: (8) after (6,7), else two
-                const int cbn = e == 4 ? cb + 1 : cb, tn0 = e == 4 ? 0 : t0 + 2;
+            for (int e = 0; e < NE; ++e) {
+                const int t0 = 2 * e, ne = (t0 + 1 < NTAPS) ? 2 : 1;      // this event's taps
+                const bool last = e == NE - 1;
+                const int nn = last ? (NTAPS >= 2 ? 2 : 1) : ((t0 + 3 < NTAPS) ? 2 : 1);   // taps of the NEXT event
+                const int cbn = last ? cb + 1 : cb, tn0 = last ? 0 : t0 + 2;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 int sl = slot_c + ne;
@@ -604,9 +633,12 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u < ne) {
-                        const int t = t0 + u;
-                        const bool own = t < NPW && (t * 8 + wave) * 8 < prows;
-                        issue_piece(cb + 1, own ? poff[t < NPW ? t : 0] : poff[0], own ? t : 0);
+#pragma unroll
+                        for (int q = 0; q < PPT; ++q) {                   // PPT patch pieces of the next block per tap
+                            const int t = (t0 + u) * PPT + q;
+                            const bool own = t < NPW && (t * 8 + wave) * 8 < prows;
+                            issue_piece(cb + 1, own ? poff[t < NPW ? t : 0] : poff[0], own ? t : 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -678,22 +710,27 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     // must not land on a staged tile, and what __syncthreads() happens to emit is not a contract
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if (NTAPS == 4 && !dgr) {
+        if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, false, NTAPS == 4>(g, wgc, acc, smem, m0, n0);
+        else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true, NTAPS == 4>(g, wgc, acc, smem, mbase, n0, tw, W);
+        return;
+    }
     if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES>(g, wgc, acc, smem, m0, n0);
     else ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, true>(g, wgc, acc, smem, mbase, n0, tw, W);
 }
 
-template <int BM, int NJ, int BSTAGES, int PMAX>
+template <int BM, int NJ, int BSTAGES, int PMAX, int NTAPS = 9>
 __global__ __launch_bounds__(NT, 2) void conv_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes, int tw) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[halo_smem_bytes(NJ, BSTAGES, PMAX)];
-    conv_halo_body<BM, NJ, BSTAGES, PMAX>(g, a_bytes, b_bytes, tw, lc_plain(), smem);
+    conv_halo_body<BM, NJ, BSTAGES, PMAX, NTAPS>(g, a_bytes, b_bytes, tw, lc_plain(), smem);
 }
-template <int BM, int NJ, int BSTAGES, int PMAX>
+template <int BM, int NJ, int BSTAGES, int PMAX, int NTAPS = 9>
 __global__ __launch_bounds__(NT, 2) void conv_halo_group_kernel(pdmk_gemm_group_dev gg) {      // aux0 = tile width of the problem
     __shared__ __attribute__((aligned(1024))) unsigned char smem[halo_smem_bytes(NJ, BSTAGES, PMAX)];
     int pi;
     LC wgc;
     if (!lc_group(gg, pi, wgc)) return;
-    conv_halo_body<BM, NJ, BSTAGES, PMAX>(gg.p[pi], gg.a_bytes[pi], gg.b_bytes[pi], gg.aux0[pi], wgc, smem);
+    conv_halo_body<BM, NJ, BSTAGES, PMAX, NTAPS>(gg.p[pi], gg.a_bytes[pi], gg.b_bytes[pi], gg.aux0[pi], wgc, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -762,7 +799,13 @@ __device__ __forceinline__ void wgrad_ring_body(const pdmk_gemm_args& g, int lg_
         for (int i = 0; i < PA; ++i) {
             const int piece = i * 8 + wave;
             const int kr = kt * BK + piece * (1024 / RA) + a_row;    // pixel row
-            const unsigned va = (kr < g.K && a_ok) ? ((unsigned)kr * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
+            unsigned krs = (unsigned)kr;
+            if (CONV && cg.mode >= 5 && kr < g.K) {                  // phase (a, b') of an upsampled conv: dY row of pixel (b, 2y + a, 2x + b')
+                const int hw = cg.ho * cg.wo, b = kr / hw, rem = kr - b * hw, oy = rem / cg.wo, ox = rem - oy * cg.wo;
+                const int ph = cg.mode - 5;
+                krs = (unsigned)((b * 2 * cg.ho + 2 * oy + (ph >> 1)) * (2 * cg.wo) + 2 * ox + (ph & 1));
+            }
+            const unsigned va = (kr < g.K && a_ok) ? (krs * (unsigned)g.lda + (unsigned)acol) * 2u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sa + piece * 1024), 16, (int)va, 0, 0, 0);
         }
 #pragma unroll
@@ -900,8 +943,10 @@ constexpr int kNumBase = 12;
 // power-of-two column block (images wider than a tile - the VAE encoder's 128^2..512^2 levels - are cut into
 // rows x tw blocks, e.g. 16 x 16 output pixels + halo = 324 patch rows); 0 = not eligible.
 static int halo_tile_w(const pdmk_gemm_args& g, int h, int splitk) {
-    if (g.a_mode != PDMK_A_CONV || g.conv_mode != 0 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 0;
-    if ((g.conv_ci % 8) || g.ldb != 9 * g.conv_ci || g.conv_wi < 4) return 0;
+    const bool phase = g.conv_mode >= 5 && g.conv_mode <= 12;        // 2x2 phase of an upsampling conv: the 128-row shapes only
+    if (g.a_mode != PDMK_A_CONV || !(g.conv_mode == 0 || phase) || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 0;
+    if (phase && (h < 2 || !PDMK_HALO_PAIRS || g.R || (splitk > 1))) return 0;
+    if ((g.conv_ci % 8) || g.ldb != (phase ? 4 : 9) * g.conv_ci || g.conv_wi < 4) return 0;
     if ((splitk > 1 ? splitk : 1) > (g.conv_ci + 63) / 64) return 0;
     const int bm = h < 2 ? 256 : 128, pmax = h < 2 ? 400 : 264;
     const int H = g.conv_hi, W = g.conv_wi, HW = H * W;
@@ -928,6 +973,7 @@ static bool halo_ok(const pdmk_gemm_args& g, int h, int splitk) { return halo_ti
 static int pick_config(const pdmk_gemm_args& g, int splitk) {
     enum { R256x128, R256x160, R128x128, R128x160, R64x128, R64x160, S128x128, S64x128, S64x160, R128x192, R64x192, S128x160 };
     const bool n160 = (g.N % 160) == 0 || (g.N > 256 && (g.N % 128) != 0);
+    if (g.a_mode == PDMK_A_CONV && g.conv_mode >= 5) return kNumBase + (halo_ok(g, n160 ? 2 : 3, splitk) ? (n160 ? 2 : 3) : (n160 ? 3 : 2));
     if (g.a_mode == PDMK_A_CONV && g.conv_mode == 0) {
         const long t256 = (long)((g.M + 255) / 256) * ((g.N + 159) / 160);
         const int h = (g.M >= 8192 && t256 >= 128) ? (n160 ? 0 : 1) : (n160 ? 2 : 3);
@@ -955,6 +1001,11 @@ static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_byte
     const int sk = g.splitk > 1 ? g.splitk : 1;
     const int bn = 32 * nj;
     dim3 grid(((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn), sk);
+    if (g.conv_mode >= 5) {
+        if (id == 2) hipLaunchKernelGGL((conv_halo_kernel<128, 5, 4, 264, 4>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw);
+        else hipLaunchKernelGGL((conv_halo_kernel<128, 4, 5, 264, 4>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw);
+        return hipGetLastError() == hipSuccess ? 0 : -1000;
+    }
     switch (id) {
         case 0: hipLaunchKernelGGL((conv_halo_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
         case 1: hipLaunchKernelGGL((conv_halo_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, g, (unsigned)a_bytes, (unsigned)b_bytes, tw); break;
@@ -963,6 +1014,29 @@ static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_byte
         default: return 1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -1000;
+}
+
+// pdmk.h: can the 2x2 phase form serve the nearest-x2 upsample + 3x3 conv of a [B, H, W, Ci] image to Co channels?
+extern "C" int pdmk_conv_up2_supported(int B, int H, int W, int Ci, int Co, int dtype) {
+    if (dtype != PDMK_BF16 || B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || (Ci % 32) || (Co % 32)) return 0;
+    pdmk_gemm_args g = {};
+    g.a_mode = PDMK_A_CONV;
+    g.b_mode = PDMK_B_ROWK;
+    g.dtype = PDMK_BF16;
+    g.conv_b = B;
+    g.conv_hi = g.conv_ho = H;
+    g.conv_wi = g.conv_wo = W;
+    g.M = B * H * W;
+    bool ok = true;
+    for (int dir = 0; dir < 2; ++dir) {          // forward (Ci -> Co) and input gradient (Co -> Ci)
+        g.conv_mode = dir ? 9 : 5;
+        g.conv_ci = dir ? Co : Ci;
+        g.N = dir ? Ci : Co;
+        g.K = 4 * g.conv_ci;
+        g.ldb = g.K;
+        ok = ok && (pdmk_ring::halo_tile_w(g, 2, 1) > 0 || pdmk_ring::halo_tile_w(g, 3, 1) > 0);
+    }
+    return ok ? 1 : 0;
 }
 
 int pdmk_gemm_ring_num_configs() { return pdmk_ring::kNumConfigs + kNumHalo + pdmk_gemm_rowblock_num_configs(); }
@@ -988,6 +1062,7 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
     if (id >= kNumBase && id < kNumBase + kNumHalo) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumBase);
+    if (g.a_mode == PDMK_A_CONV && g.conv_mode >= 5) return 1;       // 2x2 phase convs: halo kernels only
     if (id >= kNumConfigs + kNumHalo) return pdmk_gemm_rowblock_launch(g, st, a_bytes, b_bytes, id - (kNumConfigs + kNumHalo));
     if (id < 0) return 1;
     const int sk = g.splitk > 1 ? g.splitk : 1;
@@ -1295,6 +1370,7 @@ int pdmk_gemm_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st,
         if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
         if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
         if ((g.a_mode == PDMK_A_CONV) != conv) return 1;              // one template instantiation per launch
+        if (!halo && g.a_mode == PDMK_A_CONV && g.conv_mode >= 5) return 1;
         const int sk = g.splitk > 1 ? g.splitk : 1;
         if (halo) {
             const int h = id - kNumBase;
@@ -1311,6 +1387,14 @@ int pdmk_gemm_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st,
     G.finish(n);
     const dim3 grid(G.total);
     if (halo) {
+        bool phase = gs[0].conv_mode >= 5;
+        for (int i = 1; i < n; ++i)
+            if ((gs[i].conv_mode >= 5) != phase) return 1;
+        if (phase) {
+            if (id - kNumBase == 2) hipLaunchKernelGGL((conv_halo_group_kernel<128, 5, 4, 264, 4>), grid, dim3(NT), 0, st, G.gg);
+            else hipLaunchKernelGGL((conv_halo_group_kernel<128, 4, 5, 264, 4>), grid, dim3(NT), 0, st, G.gg);
+            return hipGetLastError() == hipSuccess ? 0 : -1000;
+        }
         switch (id - kNumBase) {
             case 0: hipLaunchKernelGGL((conv_halo_group_kernel<256, 5, 3, 400>), grid, dim3(NT), 0, st, G.gg); break;
             case 1: hipLaunchKernelGGL((conv_halo_group_kernel<256, 4, 3, 400>), grid, dim3(NT), 0, st, G.gg); break;
@@ -1357,7 +1441,7 @@ int pdmk_wgrad_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes
     if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
     const bool conv = g.b_mode == PDMK_B_COLK_CONV;
     if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
-    if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3)) return 1;
+    if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3 || g.conv_mode == 4 || g.conv_mode > 8)) return 1;
     if (id == kNumW || id == kNumW + 1) {
         if (!wgrad_halo_ok(g)) return 1;
         const int nblk = (g.K + 127) / 128, sk = g.splitk > 1 ? g.splitk : 1, bm = id == kNumW ? 64 : 128;
@@ -1405,7 +1489,7 @@ int pdmk_wgrad_ring_group_launch(const pdmk_gemm_args* gs, int n, hipStream_t st
         if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_COLK || g.b_mode == PDMK_B_ROWK || !g.out_f32) return 1;
         if ((g.b_mode == PDMK_B_COLK_CONV) != conv) return 1;
         if ((g.M % 8) || (g.N % 8) || (g.lda % 8) || (!conv && (g.ldb % 8))) return 1;
-        if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3)) return 1;
+        if (conv && ((g.conv_ci % 8) || (g.conv_ld % 8) || g.conv_mode == 3 || g.conv_mode == 4 || g.conv_mode > 8)) return 1;
         const int sk = g.splitk > 1 ? g.splitk : 1;
         if (halo) {
             if (!wgrad_halo_ok(g)) return 1;

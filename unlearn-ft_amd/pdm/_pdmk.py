@@ -50,6 +50,9 @@ _SIGS = {
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
     "pdmk_gemm_group": ([C.POINTER(GemmArgs), i32, vp, C.POINTER(i32)], i32),
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
+    "pdmk_conv_up2_supported": ([i32, i32, i32, i32, i32, i32], i32),
+    "pdmk_up2_pack_weights": ([vp, vp, vp, i32, i32, i32, vp], i32),
+    "pdmk_up2_combine_wgrad": ([vp, vp, i32, i32, vp], i32),
     "pdmk_gemm_last_candidate": ([], i32),
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
@@ -795,6 +798,19 @@ def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bias_corr, grad_scale, zero_grad, 
 
 def transpose_tiles(src, dst, table, ntiles):
     _chk(_lib.pdmk_transpose_tiles(_p(src), _p(dst), _p(table), ntiles, dt(src), _st()), "pdmk_transpose_tiles")
+
+
+def conv_up2_supported(B, H, W, Ci, Co, dtype):
+    """True when the library serves nearest-x2 upsample + 3x3 conv of a [B, H, W, Ci] image as four 2x2 phase convs."""
+    return dtype == torch.bfloat16 and bool(_lib.pdmk_conv_up2_supported(B, H, W, Ci, Co, BF16))
+
+
+def up2_pack_weights(w3, wp, wpt, Co, Ci):
+    _chk(_lib.pdmk_up2_pack_weights(_p(w3), _p(wp), _p(wpt), Co, Ci, dt(wp), _st()), "pdmk_up2_pack_weights")
+
+
+def up2_combine_wgrad(dwp, dw3, Co, Ci):
+    _chk(_lib.pdmk_up2_combine_wgrad(_p(dwp), _p(dw3), Co, Ci, _st()), "pdmk_up2_combine_wgrad")
 
 
 def sumsq(x, n, out, slot):

@@ -82,6 +82,9 @@ class UNetEngine:
         # ... the 3x3 conv weight gradients too (PDMK_WGRAD_SLABS_CONV=1): measured, no gain (43.3 vs 43.6 ms per main step:
         # their slabs are sk x 4-60 MB each), so they keep the atomics
         self.conv_slabs = os.environ.get("PDMK_WGRAD_SLABS_CONV", "0") == "1"
+        # upsampler convs as four 2x2 phase convs on the low-resolution image (PDMK_CONV_UP2=0: nearest x2 fused into the
+        # 3x3 gather, 2.25 x the multiply-accumulates)
+        self.up2 = os.environ.get("PDMK_CONV_UP2", "1") != "0"
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -257,6 +260,9 @@ class UNetEngine:
         M = B * Ho * Wo
         y = out if out is not None else self._empty(M, Cop)
         assert tuple(y.shape) == (M, Cop)
+        if (mode == 2 and self.up2 and rowvec is None and residual is None and
+                k.conv_up2_supported(B, Hi, Wi, Cip, Cop, self.dtype)):
+            return self._conv_up2(x, key, B, Hi, Wi, bias, y, e), Ho, Wo
         k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
                rowvec=rowvec.t[:, rv_cols[0]:] if rowvec is not None else None, rows_per_b=Ho * Wo,
@@ -304,6 +310,56 @@ class UNetEngine:
                     self._give(residual, dy)
             self.tape.append(bwd)
         return out, Ho, Wo
+
+    def _conv_up2(self, x, key, B, Hi, Wi, bias, y, e):
+        """Upsample2D (nearest x2 + 3x3 conv; unet_2d_conditional.py up blocks) as four 2x2 phase convs
+        on the low-resolution image (pdmk.h conv_mode 5..12): 16 instead of 36 multiply-accumulates per low-resolution pixel,
+        forward, input gradient and weight gradient alike.  The four phases of the forward and of the weight gradient are
+        independent problems of one shape: one grouped launch each (pdmk_gemm_group)."""
+        P = self.P
+        Cop, _, Cip = e.shape
+        Ml = B * Hi * Wi
+        wp, wpt = P.up2_weights(key)
+        lmacs = 4 * Ml * e.logical[0] * e.logical[1] * 4           # executed multiply-accumulates (the 3x3 form: 9 / 4 of it)
+        geo = lambda m, ci, ld: (B, Hi, Wi, ci, Hi, Wi, m, ld)
+        with k.Recorder() as r:
+            for p_ in range(4):
+                k.gemm(x.t, wp[p_], y, Ml, Cop, 4 * Cip, 0, 4 * Cip, _ld(y), a_mode=k.A_CONV, conv=geo(5 + p_, Cip, _ld(x.t)),
+                       bias=P.p(bias), macs=lmacs // 4)
+        self._issue(r.recs)
+        if self.count_macs:
+            self.macs += 4 * Ml * e.logical[0] * e.logical[1] * 9  # model MACs are counted as the reference executes them
+        out = Act(y)
+        if self.train:
+            def bwd():
+                dy = out.g
+                ldy = _ld(dy)
+                xt = x.t
+                # weight gradient: four phase problems into a zeroed [4][Co][4 Ci] buffer, then folded into the 3x3 gradient
+                dwp = k.zeros((4, Cop, 4 * Cip), self.dev, torch.float32)
+                sk = k.wgrad_plan(dy, xt, Cop, 4 * Cip, Ml, ldy, 0, k.B_COLK_CONV, geo(5, Cip, _ld(xt)))
+                with k.Recorder() as rw:
+                    for p_ in range(4):
+                        k.gemm(dy, xt, dwp[p_], Cop, 4 * Cip, Ml, ldy, 0, 4 * Cip, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
+                               conv=geo(5 + p_, Cip, _ld(xt)), out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(xt),
+                               colsum_out=P.g(bias), macs=lmacs // 4)
+                self._issue(rw.recs)
+                k.up2_combine_wgrad(dwp, P.g(key + ".weight"), Cop, Cip)
+                if x.rg:
+                    dx, acc = self._grad_into(x, Ml, Cip)
+                    for p_ in range(4):      # the four phases add into the same low-resolution gradient: one after the other
+                        k.gemm(dy, wpt[p_], dx, Ml, Cip, 4 * Cop, 0, 4 * Cop, _ld(dx), a_mode=k.A_CONV,
+                               conv=geo(9 + p_, Cop, ldy), accumulate=(acc or p_ > 0), macs=lmacs // 4)
+            self.tape.append(bwd)
+        return out
+
+    def _issue(self, recs):
+        """Independent GEMM records of one shape: one grouped launch (or, while an outer lockstep recording is active, handed
+        on to it one by one)."""
+        if k.RECORD is not None:
+            k.RECORD.extend(recs)
+        else:
+            k.gemm_group(recs)
 
     def groupnorm(self, x, key, B, HW, G, gs, eps, silu):
         P = self.P

@@ -298,12 +298,33 @@ class ParamStore:
         tab = np.where(tab >= 2 ** 31, tab - 2 ** 32, tab).astype(np.int32)
         return torch.from_numpy(tab).to(self.master.device), tab.shape[0]
 
+    # ---- upsampler convs as four 2x2 phase convs (engine.conv3 mode 2, pdmk.h conv_mode 5..12): the phase weights are
+    # derived copies like w / wt, re-packed from the fp32 master after every optimiser step
+    def up2_weights(self, key):
+        """(wp [4, Co, 4 Ci], wpt [4, Ci, 4 Co] or None) of the 3x3 conv `key`, packed on first use."""
+        if not hasattr(self, "_up2"):
+            self._up2 = {}
+        if key not in self._up2:
+            e = self.by_key[key + ".weight"]
+            co, _, ci = e.shape
+            wp = torch.empty((4, co, 4 * ci), device=self.master.device, dtype=self.dtype)
+            wpt = torch.empty((4, ci, 4 * co), device=self.master.device, dtype=self.dtype) if self.train else None
+            self._up2[key] = (wp, wpt)
+            k.up2_pack_weights(self.p(key + ".weight"), wp, wpt, co, ci)
+        return self._up2[key]
+
+    def refresh_up2(self):
+        for key, (wp, wpt) in getattr(self, "_up2", {}).items():
+            e = self.by_key[key + ".weight"]
+            k.up2_pack_weights(self.p(key + ".weight"), wp, wpt, e.shape[0], e.shape[2])
+
     def refresh(self, w_is_fresh=False, wt=True):
         """master -> w (cast) -> wt (tiled transposes), two launches.  `w_is_fresh`: the fused AdamW already wrote w.
         `wt=False` leaves the transposed (dgrad) copies to a later `refresh_wt()` - they are not read before the next
         backward pass, so the stepper launches that pass beside the next forward instead of after the optimiser."""
         if self.dtype != torch.float32 and not w_is_fresh:
             k.cast_permute(self.master, self.w, self.total, 1, 1, 0)
+        self.refresh_up2()
         if wt:
             self.refresh_wt()
 
