@@ -1050,7 +1050,7 @@ def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
     w3 = rnd((Co, 9 * Ci), dev, torch.float32, 0.05)            # packed [Co][9][Ci] fp32 master
     bias = rnd((Co,), dev, torch.float32)
     wp = torch.empty(4, Co, 4 * Ci, device=dev, dtype=dt)
-    wpt = torch.empty(4, Ci, 4 * Co, device=dev, dtype=dt)
+    wpt = torch.empty(Ci, 16 * Co, device=dev, dtype=dt)          # [Ci][phase][tap][Co]
     k.up2_pack_weights(w3, wp, wpt, Co, Ci)
     geo = lambda m, ci, ld: (B, H, W, ci, H, W, m, ld)
     Ml, Mh = B * H * W, B * 4 * H * W
@@ -1067,11 +1067,17 @@ def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
     close(y.float(), yr.permute(0, 2, 3, 1).reshape(Mh, Co), 2e-2, "up2 forward")
     dy = rnd((Mh, Co), dev, dt)
     yr.backward(dy.float().view(B, 2 * H, 2 * W, Co).permute(0, 3, 1, 2))
-    # input gradient: the four phases accumulate
+    # input gradient: the four phases one after the other (modes 9..12, accumulating; a phase's weights are a column slice of
+    # wpt), and all four as ONE problem (mode 13)
     dx = torch.zeros(Ml, Ci, device=dev, dtype=dt)
     for p in range(4):
-        k.gemm(dy, wpt[p], dx, Ml, Ci, 4 * Co, 0, 4 * Co, Ci, a_mode=k.A_CONV, conv=geo(9 + p, Co, Co), accumulate=p > 0)
+        k.gemm(dy, wpt[:, p * 4 * Co:(p + 1) * 4 * Co], dx, Ml, Ci, 4 * Co, 0, 16 * Co, Ci, a_mode=k.A_CONV,
+               conv=geo(9 + p, Co, Co), accumulate=p > 0)
     close(dx.float(), xr.grad.permute(0, 2, 3, 1).reshape(Ml, Ci), 3e-2, "up2 dgrad")
+    dx1 = torch.zeros(Ml, Ci + 32, device=dev, dtype=dt)
+    k.gemm(dy, wpt, dx1[:, :Ci], Ml, Ci, 16 * Co, 0, 16 * Co, Ci + 32, a_mode=k.A_CONV, conv=geo(13, Co, Co))
+    close(dx1[:, :Ci].float(), xr.grad.permute(0, 2, 3, 1).reshape(Ml, Ci), 2e-2, "up2 dgrad (merged phases)")
+    assert float(dx1[:, Ci:].abs().max()) == 0.0
     # weight / bias gradient
     dwp = torch.zeros(4, Co, 4 * Ci, device=dev)
     db = torch.zeros(Co, device=dev)
@@ -1095,4 +1101,4 @@ def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
                 ref = sum(w9[:, ky, kx] for ky in S[(a, dy_)] for kx in S[(b, dx_)])
                 got = wp[p].view(Co, 2, 2, Ci)[:, dy_, dx_]
                 assert torch.equal(got, ref.to(dt)), (p, dy_, dx_)
-                assert torch.equal(wpt[p].view(Ci, 2, 2, Co)[:, 1 - dy_, 1 - dx_], got.t())
+                assert torch.equal(wpt.view(Ci, 4, 2, 2, Co)[:, p, 1 - dy_, 1 - dx_], got.t())

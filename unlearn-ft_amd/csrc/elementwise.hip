@@ -511,8 +511,8 @@ __device__ __forceinline__ int up2_lo(int a, int d) { return a == 0 ? (d == 0 ? 
 __device__ __forceinline__ int up2_hi(int a, int d) { return a == 0 ? (d == 0 ? 0 : 2) : (d == 0 ? 1 : 2); }
 __device__ __forceinline__ int up2_d(int a, int k) { return a == 0 ? (k == 0 ? 0 : 1) : (k <= 1 ? 0 : 1); }   // dy of tap ky under phase a
 
-// w3 [Co][9][Ci] fp32 master -> wp [4][Co][4][Ci] (forward) and wpt [4][Ci][4][Co] (input gradient of phase p:
-// wpt[p][ci][(e, f)][co] = wp[p][co][(1 - e, 1 - f)][ci]), both in T; the sums are formed in fp32 and rounded once
+// w3 [Co][9][Ci] fp32 master -> wp [4][Co][4][Ci] (forward) and wpt [Ci][4][4][Co] (input gradient, phase-major inside a
+// row: wpt[ci][p][(e, f)][co] = wp[p][co][(1 - e, 1 - f)][ci]), both in T; the sums are formed in fp32 and rounded once
 template <typename T>
 __global__ void up2_pack_kernel(const float* __restrict__ w3, T* __restrict__ wp, T* __restrict__ wpt, int Co, int Ci) {
     const long total = 4L * Co * 4 * Ci;
@@ -527,7 +527,7 @@ __global__ void up2_pack_kernel(const float* __restrict__ w3, T* __restrict__ wp
         for (int ky = up2_lo(a, dy); ky <= up2_hi(a, dy); ++ky)
             for (int kx = up2_lo(b, dx); kx <= up2_hi(b, dx); ++kx) s += w3[((long)co * 9 + ky * 3 + kx) * Ci + ci];
         wp[i] = from_f32<T>(s);
-        if (wpt) wpt[(((long)p * Ci + ci) * 4 + ((1 - dy) * 2 + (1 - dx))) * Co + co] = from_f32<T>(s);
+        if (wpt) wpt[(((long)ci * 4 + p) * 4 + ((1 - dy) * 2 + (1 - dx))) * Co + co] = from_f32<T>(s);
     }
 }
 // dw3 [Co][9][Ci] += the phase gradients dwp [4][Co][4][Ci]: tap (ky, kx) belongs to exactly one (dy, dx) of every phase

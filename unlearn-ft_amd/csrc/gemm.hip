@@ -744,7 +744,7 @@ static int validate_args(const pdmk_gemm_args& g) {
     if (g.b_mode == PDMK_B_ROWK && (g.ldb % ch)) return -1;
     if (g.b_mode == PDMK_B_COLK && ((g.ldb % ch) || (g.N % g4))) return -1;
     if (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) {
-        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 12) return -1;
+        if (g.conv_ci <= 0 || (g.conv_ci % g4) || (g.conv_ld % ch) || g.conv_mode < 0 || g.conv_mode > 13) return -1;
         if (g.conv_mode >= 5) {     // 2x2 phase of a nearest-x2 upsample + 3x3 conv (pdmk.h): bf16 LDS-DMA kernels only
             if (g.dtype != PDMK_BF16 || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return -2;
             if (g.b_mode == PDMK_B_COLK_CONV && g.conv_mode > 8) return -1;
@@ -753,7 +753,7 @@ static int validate_args(const pdmk_gemm_args& g) {
         if (g.conv_b <= 0 || g.conv_hi <= 0 || g.conv_wi <= 0 || g.conv_ho <= 0 || g.conv_wo <= 0) return -1;
         const long px = (long)g.conv_b * g.conv_ho * g.conv_wo;
         if (px >= (1L << 30) || (long)g.conv_b * g.conv_hi * g.conv_wi >= (1L << 30)) return -1;   // 32-bit pixel ids
-        const int ntaps = g.conv_mode >= 5 ? 4 : 9;
+        const int ntaps = g.conv_mode == 13 ? 16 : (g.conv_mode >= 5 ? 4 : 9);
         if (g.a_mode == PDMK_A_CONV && (g.M != px || g.K != ntaps * g.conv_ci)) return -1;
         if (g.b_mode == PDMK_B_COLK_CONV && (g.K != px || g.N != ntaps * g.conv_ci)) return -1;
         // gather geometry must be consistent with the source extent (out-of-image taps read as zero padding)
@@ -909,12 +909,19 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
     }, st, e0, e1);
     int best = -1;
     float bt = t_sep * 0.98f;                           // a group must win by > 2 %
-    for (int i = 0; i < n; ++i) {
-        bool seen = ids[i] <= 0;
-        for (int j = 0; j < i; ++j) seen = seen || ids[j] == ids[i];
+    // candidates: the members' own plans, the static heuristic's pick for the first member and - for convs - the halo shapes
+    // (a shape that loses as a single 256-workgroup launch can win once four problems fill the grid)
+    int cands[PDMK_GEMM_GROUP_MAX + 5], nc = 0;
+    for (int i = 0; i < n; ++i) cands[nc++] = ids[i];
+    cands[nc++] = heuristic_cfg(a[0]);
+    if (a[0].a_mode == PDMK_A_CONV)
+        for (int h = 0; h < 4; ++h) cands[nc++] = 1 + 12 + h;            // 1 + kNumBase + h (gemm_ring.hip)
+    for (int i = 0; i < nc; ++i) {
+        bool seen = cands[i] <= 0;
+        for (int j = 0; j < i; ++j) seen = seen || cands[j] == cands[i];
         if (seen) continue;
-        const float tg = time_us([&]() -> int { return group_launch(t, n, st, ids[i]); }, st, e0, e1);
-        if (tg < bt) { bt = tg; best = ids[i]; }
+        const float tg = time_us([&]() -> int { return group_launch(t, n, st, cands[i]); }, st, e0, e1);
+        if (tg < bt) { bt = tg; best = cands[i]; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);

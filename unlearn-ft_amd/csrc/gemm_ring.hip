@@ -456,10 +456,13 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     static_assert(PMAX % 8 == 0 && (NTAPS == 4 || NPW <= 9 - (BSTAGES - 1)), "whole pieces; next block's patch issued before its first weight tile");
     static_assert(NTAPS == 9 || (NTAPS == 4 && BSTAGES >= 4 && PDMK_HALO_PAIRS), "phase convs run the two-taps-per-barrier path");
     // phase geometry (NTAPS == 4): tap phase (ta, tb); strided input (in_s = 2, offsets ia, ib) for the gradient modes
+    // conv_mode 13: the input gradient through ALL four phases as one problem - K = (phase, tap, channel), the channel-block
+    // loop runs over 4 x ncb virtual blocks, each with the patch (pixel offset) and the taps of its phase
     const int phm = NTAPS == 4 ? g.conv_mode - 5 : 0;
+    const bool merged = NTAPS == 4 && phm == 8;
     const bool dgr = NTAPS == 4 && phm >= 4;
-    const int pa_ = (phm & 3) >> 1, pb_ = phm & 1;
-    const int ta = dgr ? 1 - pa_ : pa_, tb = dgr ? 1 - pb_ : pb_;
+    const int pa_ = merged ? 0 : (phm & 3) >> 1, pb_ = merged ? 0 : phm & 1;
+    const int ta0 = dgr ? 1 - pa_ : pa_, tb0 = dgr ? 1 - pb_ : pb_;
     static_assert(2 * P_BYTES + BSTAGES * B_BYTES <= 160 * 1024, "LDS");
     static_assert(64 * (BN + 4) * 4 <= 2 * P_BYTES, "epilogue staging fits the patch buffers");
     static_assert(2 * P_BYTES + BSTAGES * B_BYTES == halo_smem_bytes(NJ, BSTAGES, PMAX), "smem size of the kernel wrappers");
@@ -476,7 +479,8 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     const bool nmajor = g.a_mode != PDMK_A_COLK && g.M <= 1024 && g.N > g.M;
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int H = g.conv_hi, W = g.conv_wi, Ci = g.conv_ci, HW = H * W;
-    const int ncb_total = (Ci + 63) / 64;
+    const int ncb1 = (Ci + 63) / 64;
+    const int ncb_total = (NTAPS == 4 && g.conv_mode == 13) ? 4 * ncb1 : ncb1;
     const int per = (ncb_total + wgc.gy - 1) / wgc.gy;
     const int cb0 = wgc.by * per, cb1 = min(ncb_total, cb0 + per);
     if (cb0 >= cb1 && g.accumulate != 2) return;        // slab split-K: an empty split still writes its (zero) slab
@@ -529,20 +533,25 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     }
     const int nb_wave = NBLK_B / 8 + (wave < (NBLK_B % 8) ? 1 : 0);
 
-    auto issue_piece = [&](int cb, unsigned off, int jj) {            // piece jj of patch(cb) from source offset `off`
+    // virtual block vcb -> (phase ph, channel block): ph = 0 and the block itself except in the merged gradient mode
+    auto blk_ph = [&](int vcb) { return merged ? (vcb >= 2 * ncb1 ? (vcb >= 3 * ncb1 ? 3 : 2) : (vcb >= ncb1 ? 1 : 0)) : 0; };
+    auto issue_piece = [&](int vcb, unsigned off, int jj) {           // piece jj of patch(vcb) from source offset `off`
+        const int ph = blk_ph(vcb), cb = vcb - ph * ncb1;
         const int ch = cb * 64 + lcp * 8;
-        const unsigned va = (off != OOB && ch < Ci && cb < cb1) ? off + (unsigned)ch * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(smem + (cb & 1) * P_BYTES + (jj * 8 + wave) * 1024), 16,
+        const unsigned pho = merged ? (unsigned)((ph >> 1) * 2 * W + (ph & 1)) * (unsigned)g.conv_ld * 2u : 0u;
+        const unsigned va = (off != OOB && ch < Ci && vcb < cb1) ? off + pho + (unsigned)ch * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(smem + (vcb & 1) * P_BYTES + (jj * 8 + wave) * 1024), 16,
                                                  (int)va, 0, 0, 0);
     };
-    auto issue_b = [&](int cb, int tap, int slot) {
+    auto issue_b = [&](int vcb, int tap, int slot) {
         unsigned char* sb = bring + slot * B_BYTES;
+        const int ph = blk_ph(vcb), cb = vcb - ph * ncb1;
         const int ch = cb * 64 + lcb * 8;
-        const unsigned koff = (unsigned)(tap * Ci + ch) * 2u;
+        const unsigned koff = (unsigned)((ph * 4 + tap) * Ci + ch) * 2u;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i * 8 + wave < NBLK_B) {
-                const unsigned vb = (b_base[i] != OOB && ch < Ci && cb < cb1) ? b_base[i] + koff : OOB;
+                const unsigned vb = (b_base[i] != OOB && ch < Ci && vcb < cb1) ? b_base[i] + koff : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sb + (i * 8 + wave) * 1024), 16, (int)vb, 0, 0, 0);
             }
         }
@@ -569,6 +578,7 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     const unsigned b_row = (unsigned)(wn * (16 * NJ) + fr) * 128u;
 
     // one tap: 2 x (IM x NJ) MFMAs out of the patch (shifted rows) and one weight tile
+    int ta = ta0, tb = tb0;                                          // tap phase of the block being multiplied
     auto tap_compute = [&](const unsigned char* pbuf, const unsigned char* sb, int tap) __attribute__((always_inline)) {
         const int toff = NTAPS == 4 ? (ta + (tap >> 1)) * W2 + (tb + (tap & 1)) : (tap / 3) * W2 + (tap % 3);
 #pragma unroll
@@ -611,6 +621,11 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
         constexpr int PPT = NTAPS == 9 ? 1 : (NPW + NTAPS - 1) / NTAPS;
         for (int cb = cb0; cb < cb1; ++cb) {
             const unsigned char* pbuf = smem + (cb & 1) * P_BYTES;
+            if (merged) {                                             // gradient through phase ph uses the taps of phase (1 - a, 1 - b')
+                const int ph = blk_ph(cb);
+                ta = 1 - (ph >> 1);
+                tb = 1 - (ph & 1);
+            }
 #pragma unroll
             for (int i = 0; i < IM; ++i) asm volatile("" : "+v"(prow0[i]));
 #pragma unroll
@@ -943,10 +958,12 @@ constexpr int kNumBase = 12;
 // power-of-two column block (images wider than a tile - the VAE encoder's 128^2..512^2 levels - are cut into
 // rows x tw blocks, e.g. 16 x 16 output pixels + halo = 324 patch rows); 0 = not eligible.
 static int halo_tile_w(const pdmk_gemm_args& g, int h, int splitk) {
-    const bool phase = g.conv_mode >= 5 && g.conv_mode <= 12;        // 2x2 phase of an upsampling conv: the 128-row shapes only
+    const bool phase = g.conv_mode >= 5 && g.conv_mode <= 13;        // 2x2 phase(s) of an upsampling conv: the 128-row shapes only
     if (g.a_mode != PDMK_A_CONV || !(g.conv_mode == 0 || phase) || g.conv_ho != g.conv_hi || g.conv_wo != g.conv_wi) return 0;
     if (phase && (h < 2 || !PDMK_HALO_PAIRS || g.R || (splitk > 1))) return 0;
-    if ((g.conv_ci % 8) || g.ldb != (phase ? 4 : 9) * g.conv_ci || g.conv_wi < 4) return 0;
+    // (a phase's weights may be a column slice of the [N][16 ci] matrix of all four: ldb is then the full row)
+    if ((g.conv_ci % 8) || g.conv_wi < 4) return 0;
+    if (phase ? ((g.ldb % 8) || g.ldb < (g.conv_mode == 13 ? 16 : 4) * g.conv_ci) : g.ldb != 9 * g.conv_ci) return 0;
     if ((splitk > 1 ? splitk : 1) > (g.conv_ci + 63) / 64) return 0;
     const int bm = h < 2 ? 256 : 128, pmax = h < 2 ? 400 : 264;
     const int H = g.conv_hi, W = g.conv_wi, HW = H * W;
@@ -1029,10 +1046,10 @@ extern "C" int pdmk_conv_up2_supported(int B, int H, int W, int Ci, int Co, int 
     g.M = B * H * W;
     bool ok = true;
     for (int dir = 0; dir < 2; ++dir) {          // forward (Ci -> Co) and input gradient (Co -> Ci)
-        g.conv_mode = dir ? 9 : 5;
+        g.conv_mode = dir ? 13 : 5;
         g.conv_ci = dir ? Co : Ci;
         g.N = dir ? Ci : Co;
-        g.K = 4 * g.conv_ci;
+        g.K = (dir ? 16 : 4) * g.conv_ci;
         g.ldb = g.K;
         ok = ok && (pdmk_ring::halo_tile_w(g, 2, 1) > 0 || pdmk_ring::halo_tile_w(g, 3, 1) > 0);
     }

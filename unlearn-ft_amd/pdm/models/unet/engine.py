@@ -260,7 +260,7 @@ class UNetEngine:
         M = B * Ho * Wo
         y = out if out is not None else self._empty(M, Cop)
         assert tuple(y.shape) == (M, Cop)
-        if (mode == 2 and self.up2 and rowvec is None and residual is None and
+        if (mode == 2 and getattr(self, 'up2', False) and rowvec is None and residual is None and
                 k.conv_up2_supported(B, Hi, Wi, Cip, Cop, self.dtype)):
             return self._conv_up2(x, key, B, Hi, Wi, bias, y, e), Ho, Wo
         k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
@@ -335,21 +335,38 @@ class UNetEngine:
                 dy = out.g
                 ldy = _ld(dy)
                 xt = x.t
-                # weight gradient: four phase problems into a zeroed [4][Co][4 Ci] buffer, then folded into the 3x3 gradient
-                dwp = k.zeros((4, Cop, 4 * Cip), self.dev, torch.float32)
-                sk = k.wgrad_plan(dy, xt, Cop, 4 * Cip, Ml, ldy, 0, k.B_COLK_CONV, geo(5, Cip, _ld(xt)))
-                with k.Recorder() as rw:
-                    for p_ in range(4):
-                        k.gemm(dy, xt, dwp[p_], Cop, 4 * Cip, Ml, ldy, 0, 4 * Cip, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
-                               conv=geo(5 + p_, Cip, _ld(xt)), out_f32=True, splitk=sk, accumulate=(sk == 1), dtype=k.dt(xt),
-                               colsum_out=P.g(bias), macs=lmacs // 4)
-                self._issue(rw.recs)
-                k.up2_combine_wgrad(dwp, P.g(key + ".weight"), Cop, Cip)
-                if x.rg:
+                # small low-resolution grids (8x8 -> 16x16 at B = 8: 512 pixels) leave the phase forms of the two gradients with
+                # too few workgroups: there the 3x3 forms at the high resolution stay (same arithmetic, measured faster -
+                # tools/up2_bench.py)
+                # (one MI355X, B = 8, us: weight gradient 32->64 329 -> 262, 16->32 329 -> 279, 8->16 98 -> 145; input gradient
+                # 32->64 221 -> 134, 16->32 207 -> 204, 8->16 76 -> 203; forward 301 -> 139, 248 -> 123, 80 -> 55)
+                phase_w, phase_d = Ml >= 2048, Ml >= 8192
+                if phase_w:
+                    # weight gradient: four phase problems into a zeroed [4][Co][4 Ci] buffer, then folded into the 3x3 gradient
+                    dwp = k.zeros((4, Cop, 4 * Cip), self.dev, torch.float32)
+                    sk = k.wgrad_plan(dy, xt, Cop, 4 * Cip, Ml, ldy, 0, k.B_COLK_CONV, geo(5, Cip, _ld(xt)))
+                    with k.Recorder() as rw:
+                        for p_ in range(4):
+                            k.gemm(dy, xt, dwp[p_], Cop, 4 * Cip, Ml, ldy, 0, 4 * Cip, a_mode=k.A_COLK, b_mode=k.B_COLK_CONV,
+                                   conv=geo(5 + p_, Cip, _ld(xt)), out_f32=True, splitk=sk, accumulate=(sk == 1),
+                                   dtype=k.dt(xt), colsum_out=P.g(bias), macs=lmacs // 4)
+                    self._issue(rw.recs)
+                    k.up2_combine_wgrad(dwp, P.g(key + ".weight"), Cop, Cip)
+                else:
+                    k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, 4 * Ml, ldy, 0, b_mode=k.B_COLK_CONV,
+                            conv=(B, Hi, Wi, Cip, 2 * Hi, 2 * Wi, 2, _ld(xt)), macs=lmacs * 9 // 4, colsum_out=P.g(bias))
+                if x.rg and phase_d:
+                    # input gradient: all four phases as ONE problem (conv_mode 13: K = (phase, tap, channel))
                     dx, acc = self._grad_into(x, Ml, Cip)
-                    for p_ in range(4):      # the four phases add into the same low-resolution gradient: one after the other
-                        k.gemm(dy, wpt[p_], dx, Ml, Cip, 4 * Cop, 0, 4 * Cop, _ld(dx), a_mode=k.A_CONV,
-                               conv=geo(9 + p_, Cop, ldy), accumulate=(acc or p_ > 0), macs=lmacs // 4)
+                    k.gemm(dy, wpt, dx, Ml, Cip, 16 * Cop, 0, 16 * Cop, _ld(dx), a_mode=k.A_CONV, conv=geo(13, Cop, ldy),
+                           accumulate=acc, macs=lmacs)
+                elif x.rg:
+                    tmp = self._empty(4 * Ml, Cip)
+                    k.gemm_auto(dy, P.wtv(key + ".weight"), tmp, 4 * Ml, Cip, 9 * Cop, 0, 9 * Cop, Cip, a_mode=k.A_CONV,
+                                conv=(B, 2 * Hi, 2 * Wi, Cop, 2 * Hi, 2 * Wi, 0, ldy), macs=lmacs * 9 // 4)
+                    pooled = self._empty(Ml, Cip)
+                    k.pool2x2_sum(tmp, pooled, B, Hi, Wi, Cip)
+                    self._give(x, pooled)
             self.tape.append(bwd)
         return out
 

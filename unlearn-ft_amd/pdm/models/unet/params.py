@@ -301,14 +301,14 @@ class ParamStore:
     # ---- upsampler convs as four 2x2 phase convs (engine.conv3 mode 2, pdmk.h conv_mode 5..12): the phase weights are
     # derived copies like w / wt, re-packed from the fp32 master after every optimiser step
     def up2_weights(self, key):
-        """(wp [4, Co, 4 Ci], wpt [4, Ci, 4 Co] or None) of the 3x3 conv `key`, packed on first use."""
+        """(wp [4, Co, 4 Ci], wpt [Ci, 16 Co] (phase-major inside a row) or None) of the 3x3 conv `key`, packed on first use."""
         if not hasattr(self, "_up2"):
             self._up2 = {}
         if key not in self._up2:
             e = self.by_key[key + ".weight"]
             co, _, ci = e.shape
             wp = torch.empty((4, co, 4 * ci), device=self.master.device, dtype=self.dtype)
-            wpt = torch.empty((4, ci, 4 * co), device=self.master.device, dtype=self.dtype) if self.train else None
+            wpt = torch.empty((ci, 16 * co), device=self.master.device, dtype=self.dtype) if self.train else None
             self._up2[key] = (wp, wpt)
             k.up2_pack_weights(self.p(key + ".weight"), wp, wpt, co, ci)
         return self._up2[key]
