@@ -789,7 +789,9 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
         const int rc = launch_candidate(g, st, g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
         g_last_candidate = rc == 1 ? 0 : (g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
         if (g.epilogue && rc == 1) return -2;
-        return rc == 1 ? launch_legacy(g, st) : rc;
+        const bool phase = (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) && g.conv_mode >= 5;
+        if (!(phase && rc == 1)) return rc == 1 ? launch_legacy(g, st) : rc;
+        // a 2x2 phase conv the forced candidate does not serve has no K-step-32 form to fall back to: its own plan below
     }
     const int sk = g.splitk > 1 ? g.splitk : 1;
     int id;
