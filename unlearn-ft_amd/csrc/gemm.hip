@@ -613,6 +613,12 @@ int launch_candidate(const pdmk_gemm_args& g, hipStream_t st, int id) {
     return pdmk_gemm_ring_launch(g, st, ab, bb, id - 1);
 }
 
+// rows of C a problem may write: a forward phase of an upsampling conv (conv_mode 5..8) stores row m at a pixel of the
+// 2hi x 2wi image, i.e. anywhere in 4 M rows
+long out_rows(const pdmk_gemm_args& g) {
+    return (g.a_mode == PDMK_A_CONV && g.conv_mode >= 5 && g.conv_mode <= 8) ? 4L * g.M : (long)g.M;
+}
+
 bool can_tune(hipStream_t st) {
     if (!tune_mode() || !ring_mode()) return false;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -663,7 +669,7 @@ float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws,
 
 // best candidate for (shape, sk); *t_out = its time.  Caller holds g_plan_mu and has checked can_tune().
 int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
-    const size_t out_bytes = (size_t)g.M * g.N * 4;
+    const size_t out_bytes = (size_t)out_rows(g) * g.N * 4;
     if (!ensure_scratch((size_t)(sk > 1 ? sk : 1) * out_bytes + out_bytes + (size_t)g.M * 4 + 256)) return -1;
     (void)hipDeviceSynchronize();                    // other streams (teacher branch) must not overlap the timings
     hipEvent_t e0, e1;
@@ -879,7 +885,7 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
     size_t off[PDMK_GEMM_GROUP_MAX + 1];
     off[0] = 0;
     for (int i = 0; i < n; ++i) {
-        const size_t out = (size_t)a[i].M * (size_t)a[i].N * 4;
+        const size_t out = (size_t)out_rows(a[i]) * (size_t)a[i].N * 4;
         const size_t slabs = (a[i].accumulate == 2 && a[i].splitk > 1) ? (size_t)a[i].splitk : 1;
         off[i + 1] = off[i] + ((out * slabs + (size_t)a[i].M * 4 + 1023) & ~(size_t)1023);
     }
