@@ -4,10 +4,9 @@ forward-diffusion kernel that opens each one).  usage: tools/rocpd_step.py <resu
 import re, sqlite3, sys, collections
 con = sqlite3.connect(sys.argv[1])
 rows = con.execute("select start, end, name, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
-ad = []                                                          # first kernel of every step: the forward-diffusion kernel
-for i, r in enumerate(rows):                                     # (round 3: the teacher graph has one of its own a few us later -
-    if "noise_kernel" in r[2] and (not ad or r[0] - rows[ad[-1]][0] > 2_000_000):    # marks closer than 2 ms are one step)
-        ad.append(i)
+ad = [i for i, r in enumerate(rows) if "noise_kernel" in r[2]]   # forward-diffusion kernels: TWO per step since round 3 (the
+ad = ad[::2]                                                     # teacher graph and the student's forward graph each open with
+                                                                 # one, a few us to a few ms apart): every second one opens a step
 si = int(sys.argv[2]) if len(sys.argv) > 2 else len(ad) // 2
 seg = rows[ad[si]: ad[si + 1]]
 def short(n):
