@@ -309,14 +309,36 @@ class ParamStore:
             co, _, ci = e.shape
             wp = torch.empty((4, co, 4 * ci), device=self.master.device, dtype=self.dtype)
             wpt = torch.empty((ci, 16 * co), device=self.master.device, dtype=self.dtype) if self.train else None
-            self._up2[key] = (wp, wpt)
-            k.up2_pack_weights(self.p(key + ".weight"), wp, wpt, co, ci)
-        return self._up2[key]
+            self._up2[key] = (wp, wpt, self._up2_table(co, ci) if wpt is not None else None)
+            k.up2_pack_weights(self.p(key + ".weight"), wp, None, co, ci)
+            if wpt is not None:
+                k.transpose_tiles(wp, wpt, *self._up2[key][2])
+        return self._up2[key][:2]
+
+    def _up2_table(self, co, ci):
+        """64x64-tile records (pdmk_transpose_tiles) for wpt[ci][p][3 - j][co] = wp[p][co][j][ci]: sixteen [Co][Ci] -> [Ci][Co]
+        transposes (the pack kernel writes wp coalesced; writing the transposed copy from it as well was uncoalesced and
+        took 170 us per conv - 0.5 ms of every step)."""
+        import numpy as np
+        recs = []
+        for p_ in range(4):
+            for j in range(4):
+                so, do = p_ * co * 4 * ci + j * ci, (p_ * 4 + (3 - j)) * co
+                rr, cc = np.meshgrid(np.arange(0, co, 64), np.arange(0, ci, 64), indexing="ij")
+                t = np.zeros((rr.size, 12), dtype=np.int64)
+                t[:, 0], t[:, 2] = so, do
+                t[:, 4], t[:, 5], t[:, 6], t[:, 7] = co, ci, 4 * ci, 16 * co
+                t[:, 8], t[:, 9] = rr.ravel(), cc.ravel()
+                recs.append(t)
+        tab = np.concatenate(recs, 0).astype(np.int32)
+        return torch.from_numpy(tab).to(self.master.device), tab.shape[0]
 
     def refresh_up2(self):
-        for key, (wp, wpt) in getattr(self, "_up2", {}).items():
+        """Forward phase weights from the fp32 master (main stream, after the optimiser: the up blocks of the next forward
+        read them); the transposed copies follow with the other dgrad copies (refresh_wt)."""
+        for key, (wp, wpt, tab) in getattr(self, "_up2", {}).items():
             e = self.by_key[key + ".weight"]
-            k.up2_pack_weights(self.p(key + ".weight"), wp, wpt, e.shape[0], e.shape[2])
+            k.up2_pack_weights(self.p(key + ".weight"), wp, None, e.shape[0], e.shape[2])
 
     def refresh(self, w_is_fresh=False, wt=True):
         """master -> w (cast) -> wt (tiled transposes), two launches.  `w_is_fresh`: the fused AdamW already wrote w.
@@ -333,6 +355,9 @@ class ParamStore:
             if not hasattr(self, "_tiles"):
                 self._tiles = self._tile_table()
             k.transpose_tiles(self.w, self.wt, self._tiles[0], self._tiles[1])
+            for key, (wp, wpt, tab) in getattr(self, "_up2", {}).items():
+                if wpt is not None:
+                    k.transpose_tiles(wp, wpt, tab[0], tab[1])
 
     # ---- state dict interchange (diffusers names, pruned shapes)
     @torch.no_grad()
