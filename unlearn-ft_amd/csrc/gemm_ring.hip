@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#ifndef PDMK_WGRAD_XCD
+#define PDMK_WGRAD_XCD 1      // weight gradients: all tiles of a split on one XCD (0: split = blockIdx.y, tiles round-robin)
+#endif
 #ifndef PDMK_HALO_PAIRS
 #define PDMK_HALO_PAIRS 1     // halo conv, rings of >= 4 slots: two taps per barrier (0: one, as in round 1)
 #endif
@@ -35,6 +38,19 @@ struct LC {
     unsigned bx, by, gx, gy;
 };
 __device__ __forceinline__ LC lc_plain() { return LC{blockIdx.x, blockIdx.y, gridDim.x, gridDim.y}; }
+// Split launches (weight gradients: the reduction is cut into gridDim.y splits): ALL tiles of one split on ONE XCD.  The tiles
+// of a split read the same k-rows of both operands (different column tiles); dealt round-robin over the 8 XCDs by their linear
+// id they fetch those rows through up to 8 different L2s (PMC, round 2/3: 90 MB read per launch of the 320 x 320 Linear weight
+// gradient against 42 MB of operands).  The linear id is mapped to an XCD-major logical id first (the workgroups of one XCD
+// get consecutive ids), and that id is (split, tile) with the tile fastest - which split lands on which XCD is irrelevant,
+// and split -> k-range is unchanged, so slab sums stay bit-identical.
+__device__ __forceinline__ LC lc_split_xcd() {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    if (gy == 1) return LC{blockIdx.x, 0u, gx, 1u};
+    const unsigned t = (unsigned)xcd_remap((int)(blockIdx.y * gx + blockIdx.x), (int)(gx * gy));
+    const unsigned z = t / gx;
+    return LC{t - z * gx, z, gx, gy};
+}
 // problem of this workgroup in a grouped launch; false = padding workgroup (every problem starts on a multiple of 8 blocks,
 // so that wgc.bx % 8 - the XCD under round-robin placement - equals the local id % 8 the tile remap assumes)
 __device__ __forceinline__ bool lc_group(const pdmk_gemm_group_dev& gg, int& pi, LC& lc) {
@@ -46,8 +62,9 @@ __device__ __forceinline__ bool lc_group(const pdmk_gemm_group_dev& gg, int& pi,
     const unsigned local = b - (unsigned)gg.start[pi];
     const unsigned gx = (unsigned)gg.gx[pi], gy = (unsigned)gg.gy[pi];
     if (local >= gx * gy) return false;
-    const unsigned z = local / gx;
-    lc = LC{local - z * gx, z, gx, gy};
+    const unsigned t = gy > 1 ? (unsigned)xcd_remap((int)local, (int)(gx * gy)) : local;     // all tiles of a split on one XCD (lc_split_xcd)
+    const unsigned z = t / gx;
+    lc = LC{t - z * gx, z, gx, gy};
     return true;
 }
 
@@ -925,7 +942,7 @@ template <bool CONV, int BM, int NJ, int STAGES, int OCC>
 __global__ __launch_bounds__(NT, OCC) void wgrad_ring_kernel(pdmk_gemm_args g, int lg_wo, int lg_howo, unsigned a_bytes,
                                                              unsigned b_bytes) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_smem_bytes(BM, NJ, STAGES)];
-    wgrad_ring_body<CONV, BM, NJ, STAGES, OCC>(g, lg_wo, lg_howo, a_bytes, b_bytes, lc_plain(), smem);
+    wgrad_ring_body<CONV, BM, NJ, STAGES, OCC>(g, lg_wo, lg_howo, a_bytes, b_bytes, PDMK_WGRAD_XCD ? lc_split_xcd() : lc_plain(), smem);
 }
 template <bool CONV, int BM, int NJ, int STAGES, int OCC>
 __global__ __launch_bounds__(NT, OCC) void wgrad_ring_group_kernel(pdmk_gemm_group_dev gg) {   // aux0 / aux1 = lg_wo / lg_howo
@@ -1323,7 +1340,7 @@ __device__ __forceinline__ void conv_wgrad_halo_body(const pdmk_gemm_args& g, un
 template <int IMW, int STAGES>
 __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_kernel(pdmk_gemm_args g, unsigned a_bytes, unsigned b_bytes) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[wgrad_halo_smem_bytes(IMW, STAGES)];
-    conv_wgrad_halo_body<IMW, STAGES>(g, a_bytes, b_bytes, lc_plain(), smem);
+    conv_wgrad_halo_body<IMW, STAGES>(g, a_bytes, b_bytes, PDMK_WGRAD_XCD ? lc_split_xcd() : lc_plain(), smem);
 }
 template <int IMW, int STAGES>
 __global__ __launch_bounds__(NT, 1) void conv_wgrad_halo_group_kernel(pdmk_gemm_group_dev gg) {

@@ -280,7 +280,7 @@ class UNetEngine:
                 xt = x.t
                 self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, b_mode=k.B_COLK_CONV,
                                             conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), macs=lmacs,
-                                            colsum_out=None if rowvec is not None else P.g(bias),
+                                            colsum_out=P.g(bias),       # bias gradient fused into the weight gradient
                                             queue=None if (self.wgrad_async or not self.conv_slabs) else self.slabs),
                             dy, xt)
                 if x.rg:
@@ -298,13 +298,13 @@ class UNetEngine:
                                accumulate=acc, macs=lmacs)
                 if rowvec is not None:
                     # d(rowvec)[b] = column sums of dy over the pixels of image b, written into this block's column slice
-                    # of the batched projection's gradient; conv bias grad = their sum over b
+                    # of the batched projection's gradient (the conv bias gradient - their sum over b - comes out of the weight
+                    # gradient kernel)
                     if rowvec.g is None:
                         rowvec.g = k.zeros(tuple(rowvec.t.shape), self.dev, torch.float32)
                     dtp = rowvec.g[:, rv_cols[0]:]
                     hw = Ho * Wo
                     k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B, ldo=_ld(rowvec.g))
-                    k.colsum(dtp, P.g(bias), B, Cop, _ld(rowvec.g), accumulate=True)
                 if residual is not None:
                     self._wgrad_fence()
                     self._give(residual, dy)
