@@ -615,11 +615,7 @@ class GraphedBilevel:
         nseg = self.segments if (multi or self.stream_opt) else 1
         total = st.student.store.total
         cuts = [total * (nseg - 1 - i) // nseg for i in range(nseg - 1)]      # descending arena offsets
-        if nseg > 2 and os.environ.get("PDMK_LAST_SHARE", "1") != "0":
-            # the share below the last cut is the one whose all-reduce / AdamW nothing can hide (the backward pass is over when
-            # its gradients are final): make it small - the first ~4 % of the arena (conv_in, the first ResBlock) - and let the
-            # share above it, which still has that block's backward to run under, take the rest
-            cuts[-1] = min(cuts[-1], total // 25)
+        # (a small LAST share - the one whose AdamW nothing can hide - was measured: 43.3 vs 43.3 ms per main step, no gain)
         cs = _CapturedStep()
         cs.teacher, cs.bwd, cs.offs, cs.keep = None, [], [], []
         need_t = upper or st.need_teacher
