@@ -98,6 +98,12 @@ typedef struct pdmk_gemm_args {
  * no residual / rowvec / accumulate; served by the LDS-DMA ring kernels only (-2 otherwise: use the two-pass form). */
 #define PDMK_EPI_NONE 0
 #define PDMK_EPI_GEGLU 1
+/* epilogue = PDMK_EPI_GEGLU_BWD (round 3): the input gradient of FeedForward's second Linear taken THROUGH the GEGLU that fed it
+ * (blocks.py:44-59 backward, reached from accelerator.backward trainer.py:2782): A = dY [M, K], B = W^T rows [N, K], the
+ * [M, N] product d = dY W is the gradient of hidden * gelu(gate); C2 (INPUT) = the forward pre-activation [M, 2N] in the
+ * interleaved layout above, C [M, 2N] receives its gradient (d * gelu(gate), d * hidden * gelu'(gate)), d rounded to bf16
+ * first - bit-identical to storing d and running pdmk_geglu_bwd(layout = 1).  Same restrictions as PDMK_EPI_GEGLU, no bias. */
+#define PDMK_EPI_GEGLU_BWD 2
 
 int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
 /* Up to PDMK_GEMM_GROUP_MAX INDEPENDENT GEMMs (no problem reads what another writes) in ONE launch where the library has a

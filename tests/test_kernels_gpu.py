@@ -1102,3 +1102,32 @@ def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
                 got = wp[p].view(Co, 2, 2, Ci)[:, dy_, dx_]
                 assert torch.equal(got, ref.to(dt)), (p, dy_, dx_)
                 assert torch.equal(wpt.view(Ci, 4, 2, 2, Co)[:, p, 1 - dy_, 1 - dx_], got.t())
+
+
+@pytest.mark.parametrize("cand", [1, 4, 6, 8, 12, 17, 19, -1])
+def test_gemm_fused_geglu_backward_epilogue(dev, force_cfg, cand):
+    """PDMK_EPI_GEGLU_BWD: the input gradient of FeedForward's second Linear pushed through GEGLU's backward in the GEMM's
+    epilogue equals - bit for bit - the plain input-gradient GEMM stored in bf16 followed by pdmk_geglu_bwd(layout 1), for ring
+    tile shapes with ragged M / N / K; and fp32 autograd of hidden * gelu(gate) on the same operands."""
+    from pdm import _pdmk as k
+    if cand >= 0:
+        force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(23)
+    dt = torch.bfloat16
+    for M, Fh, C in ((515, 352, 160), (200, 48, 96), (1000, 1296, 320)):
+        dy, wt = rnd((M, C), dev, dt), rnd((Fh, C), dev, dt, C ** -0.5)        # wt rows = W^T: [F, C]
+        pre = rnd((M, 2 * Fh), dev, dt)
+        d = torch.zeros(M, Fh, device=dev, dtype=dt)
+        k.gemm(dy, wt, d, M, Fh, C, C, C, Fh)
+        ref = torch.zeros(M, 2 * Fh, device=dev, dtype=dt)
+        k.geglu_bwd(pre, d, ref, M, Fh, 2 * Fh, Fh, 2 * Fh, layout=1)
+        got = torch.full((M, 2 * Fh + 8), 3.0, device=dev, dtype=dt)[:, :2 * Fh]
+        assert k.gemm_geglu_bwd(dy, wt, pre, got, M, Fh, C, C, C)
+        assert torch.equal(got, ref), (M, Fh, C, (got.float() - ref.float()).abs().max().item())
+        # fp32 autograd on the same (bf16-rounded) operands
+        hg = pre.float().reshape(M, Fh // 8, 2, 8).clone().requires_grad_(True)
+        (hg[:, :, 0] * F.gelu(hg[:, :, 1])).reshape(M, Fh).backward((dy.float() @ wt.float().t()).to(dt).float())
+        close(got.float(), hg.grad.reshape(M, 2 * Fh), 2e-2, "fused geglu backward vs fp32")
+    os.environ["PDMK_RING_CFG"] = "0"             # the K-step-32 kernels have no such epilogue: False, never a wrong result
+    assert k.gemm_geglu_bwd(rnd((64, 32), dev, dt), rnd((32, 32), dev, dt), rnd((64, 64), dev, dt),
+                            torch.zeros(64, 64, device=dev, dtype=dt), 64, 32, 32, 32, 32) is False

@@ -497,9 +497,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
 // Every K / V fragment feeds all NQ query tiles (NQ = 2 halves the LDS reads per MFMA).
 template <typename T, int NQ>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
-                                                         const T* __restrict__ v, const T* __restrict__ d_o,
+                                                         const T* __restrict__ v, const T* __restrict__ o,
+                                                         const T* __restrict__ d_o,
                                                          const float* __restrict__ lse,
-                                                         const float* __restrict__ delta, T* __restrict__ dq, int H,
+                                                         float* __restrict__ delta, T* __restrict__ dq, int H,
                                                          int Nq, int Nk, long q_bs, int q_ld, long k_bs, int k_ld,
                                                          long v_bs, int v_ld, long o_bs, int o_ld, long dq_bs,
                                                          int dq_ld, float scale, float scale2) {
@@ -512,23 +513,45 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
     __shared__ __attribute__((aligned(16))) T Os[QROWS * RS];
     __shared__ __attribute__((aligned(16))) T Ks[2][KVB * RS];
     __shared__ __attribute__((aligned(16))) T Vs[2][KVB * RS];
+    __shared__ float dls[QROWS];                                // delta of this block's queries
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q0 = blockIdx.x * QROWS, h = blockIdx.y, b = blockIdx.z;
     const auto rq = make_rsrc(q + b * q_bs + h * D, Nq, q_ld);
     const auto ro = make_rsrc(d_o + b * o_bs + h * D, Nq, o_ld);
+    const auto rO = make_rsrc(o + b * o_bs + h * D, Nq, o_ld);
     const auto rk = make_rsrc(k + b * k_bs + h * D, Nk, k_ld);
     const auto rv = make_rsrc(v + b * v_bs + h * D, Nk, v_ld);
 
     u32x4 rk_[KIO::NR], rv_[KIO::NR];
     {
-        u32x4 rq_[QIO::NR], ro_[QIO::NR];
+        u32x4 rq_[QIO::NR], ro_[QIO::NR], rO_[QIO::NR];
         QIO::load(rq_, rq, q_ld, q0, Nq, tid);
         QIO::load(ro_, ro, o_ld, q0, Nq, tid);
+        QIO::load(rO_, rO, o_ld, q0, Nq, tid);
         KIO::load(rk_, rk, k_ld, 0, Nk, tid);
         KIO::load(rv_, rv, v_ld, 0, Nk, tid);
         QIO::store(Qs, rq_, tid);
         QIO::store(Os, ro_, tid);
+        // delta[query] = rowsum(dO * O) (the flash backward's D term), formed here from the chunks this thread holds of both
+        // tiles - chunk c = tid + i * NT is (row c / CPR, columns (c % CPR) * CH ..): the CPR threads of a row are CPR
+        // consecutive lanes - and published for the dK / dV kernel, which is launched after this one
+        constexpr int CPR = QIO::CPR, CH = QIO::CH;
+#pragma unroll
+        for (int i = 0; i < QIO::NR; ++i) {
+            const T* a = reinterpret_cast<const T*>(&ro_[i]);
+            const T* c_ = reinterpret_cast<const T*>(&rO_[i]);
+            float s_ = 0.f;
+#pragma unroll
+            for (int e = 0; e < CH; ++e) s_ += to_f32(a[e]) * to_f32(c_[e]);
+#pragma unroll
+            for (int m = 1; m < CPR; m <<= 1) s_ += __shfl_xor(s_, m, 64);
+            const int c = tid + i * NT, row = c / CPR;
+            if ((c % CPR) == 0) {
+                dls[row] = s_;
+                if (q0 + row < Nq) delta[((long)b * H + h) * Nq + q0 + row] = s_;
+            }
+        }
     }
     KIO::store(Ks[0], rk_, tid);
     KIO::store(Vs[0], rv_, tid);
@@ -545,7 +568,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
         }
         const int qi = q0 + (wave * NQ + n) * 16 + (lane & 15);
         nl2[n] = qi < Nq ? -lse[((long)b * H + h) * Nq + qi] : -INFINITY;
-        ndl[n] = qi < Nq ? -delta[((long)b * H + h) * Nq + qi] : 0.f;
+        ndl[n] = qi < Nq ? -dls[(wave * NQ + n) * 16 + (lane & 15)] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) dqt[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -681,13 +704,19 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
         !aligned_ok<T>(o, o_bs, o_ld, Nq) || !aligned_ok<T>(d_o, o_bs, o_ld, Nq) || !aligned_ok<T>(dq, dq_bs, dq_ld, Nq) ||
         !aligned_ok<T>(dk, dk_bs, dk_ld, Nk) || !aligned_ok<T>(dv, dv_bs, dv_ld, Nk))
         return -1;
-    const long total = (long)B * H * Nq;
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3((int)min(4096L, (total + NT - 1) / NT)), dim3(NT), 0, st,
-                       (const T*)o, (const T*)d_o, delta, H, Nq, o_bs, o_ld, total);
+    // (delta = rowsum(dO * O) is formed inside the dQ kernel's prologue since round 3 - it used to be a launch of its own, 32
+    // per step - so the dQ kernel goes first and the dK / dV kernel reads what it published)
     // PDMK_ATTN_NQ (with PDMK_ENV_DYNAMIC) forces 16 (1) / 32 (2) rows per wave in all three kernels
     static int forced = -1, dynamic = -1;
     if (dynamic < 0) dynamic = getenv("PDMK_ENV_DYNAMIC") ? 1 : 0;
     if (forced < 0 || dynamic) { const char* e = getenv("PDMK_ATTN_NQ"); forced = e ? atoi(e) : 0; }
+#define PDMK_DQ_ARGS (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, \
+                     v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E
+    if (forced == 2)               // 32 queries per wave: no gain in the backward (unlike the forward) - A/B only
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
+    else
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
+#undef PDMK_DQ_ARGS
     // few keys (cross-attention): also split the query sweep, or the grid is only key_blocks*H*B workgroups
     const int kblocks = (Nk + 63) / 64, qblocks = (Nq + ACfg<T>::KVB - 1) / ACfg<T>::KVB;
     int nsplit = 1;
@@ -711,13 +740,6 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false, 1>), dim3(kblocks, H, B), dim3(NT), 0, st, PDMK_DKV_ARGS, nullptr, 1);
     }
 #undef PDMK_DKV_ARGS
-#define PDMK_DQ_ARGS (const T*)q, (const T*)k, (const T*)v, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, \
-                     v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E
-    if (forced == 2)               // 32 queries per wave: no gain in the backward (unlike the forward) - A/B only
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
-    else
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
-#undef PDMK_DQ_ARGS
     PDMK_CHECK_LAUNCH();
     return 0;
 }

@@ -680,7 +680,8 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     a.accumulate = 0;
     a.splitk = sk;
     a.ldc = g.N;
-    a.C2 = nullptr;                                  // tuning writes into scratch: the optional second output is left out
+    if (g.epilogue == PDMK_EPI_GEGLU_BWD) a.ldc = 2 * g.N;    // output = gradient of the [M, 2N] pre-activation (C2 is an INPUT here)
+    else a.C2 = nullptr;                             // tuning writes into scratch: the optional second output is left out
     if (a.colsum_out)
         a.colsum_out = reinterpret_cast<float*>(reinterpret_cast<char*>(out2) + out_bytes);      // bias gradient -> scratch
     if (g.a_mode == PDMK_A_COLK) {                                              // wgrad: fp32, atomics (or slabs) for sk > 1
@@ -774,11 +775,17 @@ static int validate_args(const pdmk_gemm_args& g) {
     if (g.accumulate < 0 || g.accumulate > 2) return -1;
     if (g.rowvec && g.rows_per_b <= 0) return -1;
     if (g.epilogue != PDMK_EPI_NONE) {
-        if (g.epilogue != PDMK_EPI_GEGLU) return -2;
+        if (g.epilogue != PDMK_EPI_GEGLU && g.epilogue != PDMK_EPI_GEGLU_BWD) return -2;
         if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_ROWK || g.b_mode != PDMK_B_ROWK || g.out_f32) return -2;
-        if ((g.N % 16) || (g.ldc % 8) || (g.C2 && (g.ldc2 % 8)) || g.splitk > 1 || g.accumulate || g.R || g.rowvec ||
-            g.alpha != 1.0f || (g.K % 8))
-            return -1;
+        if (g.epilogue == PDMK_EPI_GEGLU) {
+            if ((g.N % 16) || (g.ldc % 8) || (g.C2 && (g.ldc2 % 8)) || g.splitk > 1 || g.accumulate || g.R || g.rowvec ||
+                g.alpha != 1.0f || (g.K % 8))
+                return -1;
+        } else {        // GEGLU_BWD: C [M, 2N] = gradient of the pre-activation C2 [M, 2N]; plain GEMM otherwise
+            if ((g.N % 8) || (g.ldc % 8) || !g.C2 || (g.ldc2 % 8) || g.splitk > 1 || g.accumulate || g.R || g.rowvec || g.bias ||
+                g.alpha != 1.0f || (g.K % 8) || (((uintptr_t)g.C2 | (uintptr_t)g.C) & 15))
+                return -1;
+        }
         if (!ring_mode()) return -2;
     }
     return 0;
@@ -899,7 +906,8 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
         char* base = reinterpret_cast<char*>(g_scratch) + off[i];
         t[i].C = base;
         t[i].ldc = a[i].N;
-        t[i].C2 = nullptr;
+        if (t[i].epilogue == PDMK_EPI_GEGLU_BWD) t[i].ldc = 2 * a[i].N;
+        else t[i].C2 = nullptr;
         if (t[i].accumulate == 1) t[i].accumulate = 0;
         if (t[i].epilogue == PDMK_EPI_GEGLU) t[i].ldc = a[i].N / 2;
         if (t[i].colsum_out)

@@ -194,6 +194,43 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
                 for (int r = 0; r < 8; ++r) o[r] = (bf16)((float)hb[r] * gelu_f((float)gb[r]));
                 st_stream(reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + (n >> 1)), o);
             }
+        } else if (vec8 && g.epilogue == PDMK_EPI_GEGLU_BWD) {
+            // input gradient THROUGH GEGLU (blocks.py:44-59 backward): the staged tile is d(hidden * gelu(gate))[m][n .. n+7];
+            // C2 holds the forward pre-activation [M][2N] (hidden / gate interleaved in blocks of 8) and C receives its gradient in
+            // the same layout: d hidden = d * gelu(gate), d gate = d * hidden * gelu'(gate).  d is rounded to bf16 first, so the
+            // result is bit-identical to storing d and running pdmk_geglu_bwd(layout = 1) on it.
+            const bf16* X2 = reinterpret_cast<const bf16*>(g.C2);
+            bf16x8 hb[ITEMS], gb[ITEMS];
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
+                if (item < 64 * C8 && m < g.M && n < g.N) {
+                    hb[it] = *reinterpret_cast<const bf16x8*>(X2 + (long)m * g.ldc2 + 2 * n);
+                    gb[it] = *reinterpret_cast<const bf16x8*>(X2 + (long)m * g.ldc2 + 2 * n + 8);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int item = tid + it * NT;
+                const int lr2 = item / C8, c8 = item - lr2 * C8;
+                const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
+                if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8 + 4);
+                bf16x8 dh, dg;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float d = (float)(bf16)(r < 4 ? lo[r] : hi[r - 4]);
+                    const float hv = (float)hb[it][r], gv = (float)gb[it][r];
+                    dh[r] = (bf16)(d * gelu_f(gv));
+                    dg[r] = (bf16)(d * hv * gelu_grad_f(gv));
+                }
+                st_stream(reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + 2 * n), dh);
+                st_stream(reinterpret_cast<bf16x8*>(Ct + (long)m * g.ldc + 2 * n + 8), dg);
+            }
         } else if (vec8) {
             // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
             bf16x8 rres[ITEMS], cprev[ITEMS];

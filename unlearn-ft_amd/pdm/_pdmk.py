@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDMK_LIB") or os.path.join(os.path.dirname(_HERE), "libpdmk.so")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GEGLU = 0, 1
+EPI_NONE, EPI_GEGLU, EPI_GEGLU_BWD = 0, 1, 2
 A_ROWK, A_CONV, A_COLK = 0, 1, 2
 B_ROWK, B_COLK, B_COLK_CONV = 0, 1, 2
 
@@ -675,6 +675,32 @@ def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
         RECORD.append(Rec("gemm", run, g=g, macs=macs, keep=(A, B, gl, f, bias)))
         return True
     return _launch_gemm_geglu(g, macs)
+
+
+def gemm_geglu_bwd(dy, wt, pre, dpre, M, N, K, lddy, ldwt, *, macs=None):
+    """dpre[M, 2N] = gradient of the GEGLU pre-activation `pre` [M, 2N] (interleaved layout) given dy [M, K], the gradient of the
+    Linear that consumed hidden * gelu(gate): (dy @ wt^T) pushed through GEGLU's backward in the GEMM's epilogue
+    (PDMK_EPI_GEGLU_BWD).  Returns False when the library has no fused kernel for the shape (the caller then runs the plain
+    input-gradient GEMM and pdmk_geglu_bwd)."""
+    g = GemmArgs()
+    g.A, g.B, g.C, g.C2 = _p(dy), _p(wt), _p(dpre), _p(pre)
+    g.M, g.N, g.K = M, N, K
+    g.lda, g.ldb, g.ldc, g.ldc2 = lddy, ldwt, dpre.stride(0), pre.stride(0)
+    g.a_mode, g.b_mode, g.dtype = A_ROWK, B_ROWK, dt(dy)
+    g.splitk, g.alpha = 1, 1.0
+    g.epilogue = EPI_GEGLU_BWD
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.pdmk_gemm(C.byref(g), _st())
+    if rc == -2:
+        return False
+    _chk(rc, "pdmk_gemm[geglu_bwd]")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((("bf16", A_ROWK, B_ROWK, _lib.pdmk_gemm_last_candidate()), 2.0 * (macs if macs is not None else M * N * K),
+                        e0, e1, (M, N, K, 1)))
+    return True
 
 
 @_recordable("silu_fwd")

@@ -22,10 +22,12 @@ class Act:
     pend: a second finished gradient buffer waiting to be added to `g` (the residual branch's, blocks.py:379).  Reading
     `.g` adds it first (one strided accumulate pass); the GroupNorm backward of the same tensor - the usual next writer -
     takes it as an extra addend of its own store instead, so the fan-in normally costs no pass at all."""
-    __slots__ = ("t", "_g", "rg", "pend")
+    __slots__ = ("t", "_g", "rg", "pend", "src")
 
     def __init__(self, t, rg=True):
         self.t, self._g, self.rg, self.pend = t, None, rg, None
+        self.src = None      # a GEGLU output: (pre-activation tensor, the projection's Act) - its consumer's input gradient can be
+                             # pushed through GEGLU's backward in the GEMM epilogue (PDMK_EPI_GEGLU_BWD)
 
     def flush(self):
         if self.pend is not None:
@@ -72,6 +74,7 @@ class UNetEngine:
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
         self.wgrad_stream = None          # the dedicated "wgrad" role stream, created on first use
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
+        self.fuse_geglu_bwd = os.environ.get("PDMK_FUSE_GEGLU_BWD", "1") != "0"   # same for the backward (ff.net.2's input gradient)
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
         # GroupNorm / LayerNorm affine gradients: the second-stage reductions of a whole block run as one launch at the
@@ -228,7 +231,15 @@ class UNetEngine:
                                             colsum_out=P.g(bias) if bias else None,   # bias gradient fused in
                                             queue=None if self.wgrad_async else self.slabs),
                             dy, xt)
-                if x.rg:
+                fused_g = False
+                if (x.rg and x.src is not None and x._g is None and self.fuse_geglu_bwd and self.dtype == torch.bfloat16 and
+                        k.splitk_plan(dy, P.wtv(key + ".weight"), M, Kp, Np, _ld(dy), Np) == 1):
+                    pre, proj = x.src          # gradient of the GEGLU pre-activation straight from this GEMM's epilogue
+                    dpre = self._empty(M, 2 * Kp)
+                    fused_g = k.gemm_geglu_bwd(dy, P.wtv(key + ".weight"), pre, dpre, M, Kp, Np, _ld(dy), Np, macs=lmacs)
+                    if fused_g:
+                        proj.g = dpre
+                if x.rg and not fused_g:
                     dx, acc = self._grad_into(x, M, Kp)
                     k.gemm_auto(dy, P.wtv(key + ".weight"), dx, M, Kp, Np, _ld(dy), Np, _ld(dx), accumulate=acc,
                                 macs=lmacs)
@@ -239,7 +250,11 @@ class UNetEngine:
         if geglu:
             act = Act(gl)
             if self.train:
+                act.src = (y, out)
+
                 def gbwd():               # runs BEFORE the projection's own backward: d(pre-activation) from d(gl)
+                    if out._g is not None:        # already produced by the consumer's fused epilogue (PDMK_EPI_GEGLU_BWD)
+                        return
                     out.g = self._empty(M, Np)
                     k.geglu_bwd(y, act.g, out.g, M, Np // 2, _ld(y), _ld(act.g), Np, layout=1)
                 self.tape.append(gbwd)
