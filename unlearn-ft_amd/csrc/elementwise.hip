@@ -436,25 +436,41 @@ __global__ __launch_bounds__(NT) void mse_vec_kernel(const TA* __restrict__ a, c
     const long total = rows_per_b * cc;
     const float gs = gscale * (w ? w[bi] : 1.f);
     float s = 0.f;
-    for (long i = blockIdx.x * (long)NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const long r = i / cc;
-        const int c = (int)(i - r * cc) << 3;
-        const long row = (long)bi * rows_per_b + r;
-        float x[8], y[8];
-        ld8<TA>(a + row * lda + c, x);
-        ld8<TB>(b + row * ldb + c, y);
+    // 4 independent (row, chunk) items per thread and iteration: 8 sixteen-byte loads in flight before the first use (this is a
+    // pure HBM stream).  The grid is small on purpose: every block ends in ONE double atomic on out[slot], and a few thousand
+    // same-address atomics per launch (the round-2 grid) cost more than the stream itself
+    const long step = (long)gridDim.x * NT;
+    for (long i0 = blockIdx.x * (long)NT + threadIdx.x; i0 < total; i0 += 4 * step) {
+        float x[4][8], y[4][8];
+        long off[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { x[e] -= y[e]; s += x[e] * x[e]; }
-        if (da) {
-            if (acc) {
-                ld8<TA>(da + row * ldda + c, y);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = gs * x[e] + y[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] *= gs;
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * step;
+            if (i < total) {
+                const long r = i / cc;
+                const int c = (int)(i - r * cc) << 3;
+                const long row = (long)bi * rows_per_b + r;
+                off[u] = row * ldda + c;
+                ld8<TA>(a + row * lda + c, x[u]);
+                ld8<TB>(b + row * ldb + c, y[u]);
             }
-            st8<TA>(da + row * ldda + c, x);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * step >= total) continue;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[u][e] -= y[u][e]; s += x[u][e] * x[u][e]; }
+            if (da) {
+                if (acc) {
+                    ld8<TA>(da + off[u], y[u]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][e] = gs * x[u][e] + y[u][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][e] *= gs;
+                }
+                st8<TA>(da + off[u], x[u]);
+            }
         }
     }
     s = wave_sum(s);
@@ -762,7 +778,7 @@ extern "C" int pdmk_mse_fwd_bwd(const void* a, int a_dtype, const void* b, int b
     if ((cols & 7) || (lda % va) || (ldb % vb) || (da && (ldda % va)) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) ||
         ((uintptr_t)da & 15))
         return -1;
-    dim3 grid(grid_for(rows_per_b * (cols >> 3), 512), B);
+    dim3 grid(grid_for((rows_per_b * (cols >> 3) + 3) / 4, B >= 8 ? 96 : (B >= 2 ? 256 : 512)), B);
 #define PDMK_MSEV(TA, TB)                                                                                              \
     hipLaunchKernelGGL((mse_vec_kernel<TA, TB>), grid, dim3(NT), 0, (hipStream_t)s, (const TA*)a, (const TB*)b, w, out, slot, \
                        (TA*)da, (long)rows_per_b, cols, lda, ldb, ldda, scale, gscale, accumulate)

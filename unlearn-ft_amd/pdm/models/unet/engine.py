@@ -319,7 +319,9 @@ class UNetEngine:
                         rowvec.g = k.zeros(tuple(rowvec.t.shape), self.dev, torch.float32)
                     dtp = rowvec.g[:, rv_cols[0]:]
                     hw = Ho * Wo
-                    k.colsum(dy, dtp, hw, Cop, ldy, nbatch=B, ldo=_ld(rowvec.g))
+                    # (accumulate: the slice was zeroed with the whole gradient above and is written once per backward pass - no
+                    # zero-fill launch per ResBlock)
+                    k.colsum(dy, dtp, hw, Cop, ldy, accumulate=True, nbatch=B, ldo=_ld(rowvec.g))
                 if residual is not None:
                     self._wgrad_fence()
                     self._give(residual, dy)
