@@ -88,6 +88,15 @@ typedef struct pdmk_gemm_args {
     int32_t epilogue;    /* PDMK_EPI_NONE | PDMK_EPI_GEGLU */
     int32_t ldc2;        /* row stride of C2 */
     void* C2;            /* PDMK_EPI_GEGLU: optional [M, N] copy of the pre-activation (what the backward needs), or NULL */
+    float* colstat;      /* optional (round 3): per-(image, column) statistics of the OUTPUT for the GroupNorm that reads it next
+                            (blocks.py:318-319, 348-371: every GroupNorm's input is a GEMM output) - colstat[(b * 2 + 0) * cs_ld +
+                            cs_col0 + n] += sum over the rows of image b of C[m][n] (as stored, i.e. after bias / rowvec /
+                            residual and the rounding to bf16), [(b * 2 + 1) * ...] += the sum of squares; fp32 atomics into a
+                            zeroed buffer.  pdmk_groupnorm_apply_colstat turns them into group statistics, so the statistics
+                            pass over the tensor is not needed.  bf16, rows_per_b % 64 == 0, M % 64 == 0, N % 8 == 0, no
+                            split-K / epilogue / out_f32; LDS-DMA ring and halo kernels only */
+    int32_t cs_ld;       /* floats per accumulator row (>= cs_col0 + N: a concat buffer's accumulator has one row for all its columns) */
+    int32_t cs_col0;     /* accumulator column of output column 0 */
 } pdmk_gemm_args;
 
 /* PDMK_EPI_GEGLU (GEGLUGated.forward, pdm/models/unet/blocks.py:44-59 = Linear -> chunk -> hidden * gelu_erf(gate)), fused
@@ -129,6 +138,12 @@ int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
  * bf16, LDS-DMA halo kernels (128-row tiles) / ring weight-gradient kernels only: -2 where they do not take the shape
  * (pdmk_conv_up2_supported answers beforehand; the caller then uses conv_mode 2). */
 int pdmk_conv_up2_supported(int B, int H, int W, int Ci, int Co, int dtype);
+/* GroupNorm(+SiLU) forward whose statistics come from per-(image, column) sums a producing GEMM accumulated (pdmk_gemm_args.colstat,
+ * layout [B][2][cs_ld], this tensor's columns start at cs_col0) instead of a pass over x: one launch, one read of x.  `stats`
+ * ([B][G][2]: mean, rstd) is written for the backward as by pdmk_groupnorm_fwd. */
+int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats, const float* colstat,
+                                 int cs_ld, int cs_col0, int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps,
+                                 int silu, int dtype, pdmk_stream stream);
 /* w3 [Co][9][Ci] fp32 (the packed 3x3 master weight) -> wp [4][Co][4][Ci] and (optional) wpt [4][Ci][4][Co] in `dtype`;
  * dw3 [Co][9][Ci] += the four phase gradients dwp [4][Co][4][Ci] (fp32). */
 int pdmk_up2_pack_weights(const float* w3, void* wp, void* wpt, int Co, int Ci, int dtype, pdmk_stream stream);

@@ -283,6 +283,11 @@ def test_benchmarked_configuration_matches_oracle(dev, tmp_path):
     gr = GraphedBilevel(st, B, 4, 64, 64, 77, 1024)
     gr.capture(bilevel=True)
     assert len(gr.g_main.bwd) >= 2 and (gr.g_main.teacher is None) == st.lockstep
+    # GroupNorm statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): on unless PDMK_GN_EPI=0, and then the
+    # path the captured step runs for most of its GroupNorms (the rest: split-K producers, copied concat halves)
+    gc = student.engine.gn_count
+    assert gc[0] >= 40 and (not student.engine.gn_epi or gc[1] * 2 >= gc[0]), gc
+    print("groupnorms per forward / with statistics from a GEMM epilogue:", gc)
     store = student.store
     # ---- main step: gradients only (no optimiser), replayed twice (the second replay must not see stale state)
     for _ in range(2):

@@ -1131,3 +1131,72 @@ def test_gemm_fused_geglu_backward_epilogue(dev, force_cfg, cand):
     os.environ["PDMK_RING_CFG"] = "0"             # the K-step-32 kernels have no such epilogue: the library picks a ring shape itself
     assert k.gemm_geglu_bwd(rnd((64, 32), dev, dt), rnd((32, 32), dev, dt), rnd((64, 64), dev, dt),
                             torch.zeros(64, 64, device=dev, dtype=dt), 64, 32, 32, 32, 32) in (True, False)
+
+
+@pytest.mark.parametrize("cand", [1, 2, 4, 6, 9, 10, 12, 13, 14, 15, 16, 17, 19, 21, -1])
+def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
+    """pdmk_gemm_args.colstat: the per-(image, column) sums and sums of squares of the STORED bf16 output come out of the GEMM's
+    epilogue (Linear with bias + residual, a conv with the time-embedding row vector, into an accumulator slice at a column
+    offset, accumulating over two producers), for every ring tile shape, the halo-conv shapes and the tuned plan (21 = a
+    row-block id: no such epilogue there, the library launches a ring shape itself); pdmk_groupnorm_apply_colstat on these sums
+    = pdmk_groupnorm_fwd on the tensor (unet_2d_blocks.py ResnetBlock2D norm1 / norm2, blocks.py:322-380)."""
+    from pdm import _pdmk as k
+    if cand >= 0:
+        force_cfg("PDMK_RING_CFG", cand)
+    torch.manual_seed(41)
+    dt = torch.bfloat16
+
+    def sums(y, Bn, rows):
+        yf = y.float().reshape(Bn, rows, -1)
+        return yf.sum(1), (yf * yf).sum(1)
+
+    def check(acc, col0, y, Bn, rows, what):
+        s1, s2 = sums(y, Bn, rows)
+        n = y.shape[1]
+        close(acc[:, 0, col0:col0 + n], s1, 2e-4, what + " sum")
+        close(acc[:, 1, col0:col0 + n], s2, 2e-4, what + " sum of squares")
+
+    # Linear (proj_out: bias + residual into a strided concat view), 3 images of 256 / 64 rows
+    for Bn, rows, N, K in ((3, 256, 320, 160), (2, 64, 96, 320), (5, 320, 648, 96)):
+        M = Bn * rows
+        a, w, bias = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5), torch.randn(N, device=dev)
+        res = rnd((M, N + 8), dev, dt)[:, 8:]
+        ybuf = torch.zeros(M, N + 16, device=dev, dtype=dt)
+        y = ybuf[:, 8:8 + N]
+        acc = torch.zeros(Bn, 2, N + 24, device=dev)
+        k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc, 16))
+        ref = (a.float() @ w.float().t() + bias + res.float())
+        close(y, ref, 2e-2, "linear with statistics")
+        check(acc, 16, y, Bn, rows, f"linear B{Bn} rows{rows} N{N}")
+        assert (acc[:, :, :16] == 0).all() and (acc[:, :, 16 + N:] == 0).all()
+        # a second producer adds into the same accumulator columns (fp32 atomics): twice the sums
+        k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc, 16))
+        s1, _ = sums(y, Bn, rows)
+        close(acc[:, 0, 16:16 + N], 2 * s1, 2e-4, "two producers")
+    # 3x3 conv with the per-image row vector (ResnetBlock2D conv1 + time embedding), whole-row and 2D halo tiles
+    for Bn, Hs, Ci, Co in ((2, 16, 64, 160), (1, 32, 32, 64), (3, 8, 96, 320), (2, 64, 32, 128)):
+        x = rnd((Bn, Hs, Hs, Ci), dev, dt)
+        w = rnd((Co, Ci, 3, 3), dev, dt, (9 * Ci) ** -0.5)
+        bias, rv = torch.randn(Co, device=dev), torch.randn(Bn, Co, device=dev)
+        M, rows = Bn * Hs * Hs, Hs * Hs
+        y = torch.zeros(M, Co, device=dev, dtype=dt)
+        acc = torch.zeros(Bn, 2, Co, device=dev)
+        k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci),
+               bias=bias, rowvec=rv, rows_per_b=rows, colstat=(acc, 0))
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rv[:, :, None, None]
+        close(y, ref.permute(0, 2, 3, 1).reshape(M, Co), 2e-2, "conv with statistics")
+        check(acc, 0, y, Bn, rows, f"conv B{Bn} {Hs}x{Hs} {Ci}->{Co}")
+        # GroupNorm(+SiLU) from these sums == the two-pass GroupNorm of the same tensor
+        G, gs = 32, Co // 32
+        gamma, beta = torch.randn(Co, device=dev) * 0.3 + 1, torch.randn(Co, device=dev) * 0.3
+        z0, z1 = torch.zeros_like(y), torch.zeros_like(y)
+        st0, st1 = torch.zeros(Bn, G, 2, device=dev), torch.zeros(Bn, G, 2, device=dev)
+        k.groupnorm_fwd(y, z0, gamma, beta, st0, k.groupnorm_ws(dev, Bn, G), Bn, rows, Co, Co, Co, G, gs, 1e-5, True)
+        k.groupnorm_apply_colstat(y, z1, gamma, beta, st1, acc, 0, Bn, rows, Co, Co, Co, G, gs, 1e-5, True)
+        close(st1, st0, 1e-4, "statistics from the epilogue vs the statistics pass")
+        close(z1, z0, 1e-2, "groupnorm from epilogue statistics")
+    # shapes the epilogue does not take are refused (-1), never silently skipped
+    y = torch.zeros(96, 64, device=dev, dtype=dt)
+    with pytest.raises(k.PdmkError):
+        k.gemm(rnd((96, 32), dev, dt), rnd((64, 32), dev, dt), y, 96, 64, 32, 32, 32, 64, rows_per_b=48,
+               colstat=(torch.zeros(2, 2, 64, device=dev), 0))

@@ -595,6 +595,7 @@ bool operand_bytes(const pdmk_gemm_args& g, long* ab, long* bb) {
 }
 
 int launch_legacy(const pdmk_gemm_args& g, hipStream_t st) {
+    if (g.colstat) return -2;                            // epilogue statistics: LDS-DMA kernels only
     if ((g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) && g.conv_mode >= 5) return -2;   // phase convs: LDS-DMA kernels only
     const long nblocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.splitk > 1 ? g.splitk : 1);
     long ab, bb;
@@ -680,6 +681,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     a.accumulate = 0;
     a.splitk = sk;
     a.ldc = g.N;
+    a.colstat = nullptr;                             // timing launches must not add to the caller's GroupNorm accumulators
     if (g.epilogue == PDMK_EPI_GEGLU_BWD) a.ldc = 2 * g.N;    // output = gradient of the [M, 2N] pre-activation (C2 is an INPUT here)
     else a.C2 = nullptr;                             // tuning writes into scratch: the optional second output is left out
     if (a.colsum_out)
@@ -788,6 +790,14 @@ static int validate_args(const pdmk_gemm_args& g) {
         }
         if (!ring_mode()) return -2;
     }
+    if (g.colstat) {      // GroupNorm statistics of the output from the epilogue (pdmk.h): LDS-DMA kernels, plain bf16 epilogue
+        if (g.dtype != PDMK_BF16 || g.a_mode == PDMK_A_COLK || g.b_mode != PDMK_B_ROWK || g.out_f32 || g.epilogue) return -2;
+        if (g.rows_per_b <= 0 || (g.rows_per_b % 64) || (g.M % 64) || (g.N % 8) || (g.ldc % 8) || (g.R && (g.ldr % 8)) ||
+            g.splitk > 1 || g.accumulate == 2 || g.cs_col0 < 0 || g.cs_ld < g.cs_col0 + g.N || (g.K % 8))
+            return -1;
+        if (g.a_mode == PDMK_A_CONV && g.conv_mode >= 9) return -1;
+        if (!ring_mode()) return -2;
+    }
     return 0;
 }
 
@@ -803,7 +813,7 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
         g_last_candidate = rc == 1 ? 0 : (g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
         if (g.epilogue && rc == 1) return -2;
         const bool phase = (g.a_mode == PDMK_A_CONV || g.b_mode == PDMK_B_COLK_CONV) && g.conv_mode >= 5;
-        if (!(phase && rc == 1)) return rc == 1 ? launch_legacy(g, st) : rc;
+        if (!((phase || g.colstat) && rc == 1)) return rc == 1 ? launch_legacy(g, st) : rc;
         // a 2x2 phase conv the forced candidate does not serve has no K-step-32 form to fall back to: its own plan below
     }
     const int sk = g.splitk > 1 ? g.splitk : 1;
@@ -822,8 +832,12 @@ extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
             plan_file_append('c', key, id);
         } else id = heuristic_cfg(g);                   // not cached: a later eager call may still tune it
     }
-    if (g.epilogue && id <= 0) id = 1 + pdmk_gemm_ring_pick(g);
-    const int rc = launch_candidate(g, st, id);
+    if ((g.epilogue || g.colstat) && id <= 0) id = 1 + pdmk_gemm_ring_pick(g);
+    int rc = launch_candidate(g, st, id);
+    if (g.colstat && rc == 1) {                          // a plan the statistics epilogue does not exist for (row-block kernel)
+        id = 1 + pdmk_gemm_ring_pick(g);
+        rc = launch_candidate(g, st, id);
+    }
     if (g.epilogue && rc == 1) return -2;               // no ring kernel takes this shape: the caller uses the two-pass form
     g_last_candidate = rc == 1 ? 0 : id;
     return rc == 1 ? launch_legacy(g, st) : rc;
@@ -906,6 +920,7 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
         char* base = reinterpret_cast<char*>(g_scratch) + off[i];
         t[i].C = base;
         t[i].ldc = a[i].N;
+        t[i].colstat = nullptr;
         if (t[i].epilogue == PDMK_EPI_GEGLU_BWD) t[i].ldc = 2 * a[i].N;
         else t[i].C2 = nullptr;
         if (t[i].accumulate == 1) t[i].accumulate = 0;
@@ -982,7 +997,7 @@ extern "C" int pdmk_gemm_group(const pdmk_gemm_args* a, int n, pdmk_stream strea
     std::vector<int> key;
     for (int i = 0; i < n; ++i) {
         ids[i] = member_plan(a[i], st);
-        if (a[i].epilogue && ids[i] <= 0) ids[i] = 1 + pdmk_gemm_ring_pick(a[i]);
+        if ((a[i].epilogue || a[i].colstat) && ids[i] <= 0) ids[i] = 1 + pdmk_gemm_ring_pick(a[i]);
         const PlanKey k = make_key(a[i], a[i].splitk > 1 ? a[i].splitk : 1);
         key.insert(key.end(), k.v, k.v + 10);
         key.push_back(a[i].accumulate);

@@ -117,11 +117,15 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
     constexpr int SROW = BN + 4;
     constexpr int C8 = BN / 8;                                        // 8-column chunks per tile row
     constexpr int ITEMS = (64 * C8 + NT - 1) / NT;                    // (row, chunk) items per thread and pass
+    constexpr int RS = NT / C8, CS_STRIDE = RS * C8, ITEMS_CS = (64 + RS - 1) / RS;   // the statistics epilogue's item mapping
+    constexpr bool CS_OK = RS * 2 * BN * 4 <= LDS_BYTES;   // the partials fit the (drained) ring: every forward shape (NJ >= 2)
+    static_assert(ITEMS_CS >= ITEMS && (CS_OK || NJ < 2), "statistics epilogue of the forward tile shapes");
     float* stage = reinterpret_cast<float*>(smem);
     static_assert(64 * SROW * 4 <= LDS_BYTES, "staging image must fit the ring");
     float* Cf = reinterpret_cast<float*>(g.C) + (slab ? (long)wgc.by * g.M * g.ldc : 0L);
     bf16* Ct = reinterpret_cast<bf16*>(g.C);
     const bf16* Rp = reinterpret_cast<const bf16*>(g.R);
+    float cs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cs2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // colstat sums
 #pragma unroll
     for (int pass = 0; pass < BM / 64; ++pass) {
         __syncthreads();
@@ -233,24 +237,28 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
             }
         } else if (vec8) {
             // the residual / previous-output reads are issued BEFORE the barrier so that their latency overlaps it
-            bf16x8 rres[ITEMS], cprev[ITEMS];
+            // with statistics (colstat) a thread keeps ONE 8-column chunk for the whole tile: sweeps of RS whole rows by the first
+            // RS * C8 threads (the same mapping as the plain one whenever C8 divides the workgroup: every shape but the 160-wide)
+            bf16x8 rres[ITEMS_CS], cprev[ITEMS_CS];
+            const int istride = g.colstat ? CS_STRIDE : NT;
+            const bool tid_ok = !g.colstat || tid < CS_STRIDE;
 #pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+            for (int it = 0; it < ITEMS_CS; ++it) {
+                const int item = tid + it * istride;
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
                 const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
-                const bool ok = item < 64 * C8 && m < g.M && n < g.N;
+                const bool ok = tid_ok && item < 64 * C8 && m < g.M && n < g.N;
                 const long off = out_row(m) * g.ldc + n;
                 if (ok && Rp) rres[it] = *reinterpret_cast<const bf16x8*>(Rp + (long)m * g.ldr + n);
                 if (ok && acc1 && !f32out) cprev[it] = *reinterpret_cast<const bf16x8*>(Ct + off);
             }
             __syncthreads();
 #pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int item = tid + it * NT;
+            for (int it = 0; it < ITEMS_CS; ++it) {
+                const int item = tid + it * istride;
                 const int lr2 = item / C8, c8 = item - lr2 * C8;
                 const int m = row_of(pass * 64 + lr2), n = n0 + c8 * 8;
-                if (!(item < 64 * C8 && m < g.M && n < g.N)) continue;
+                if (!(tid_ok && item < 64 * C8 && m < g.M && n < g.N)) continue;
                 float v[8];
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(stage + lr2 * SROW + c8 * 8 + 4);
@@ -288,6 +296,43 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16)v[r];
                     st_stream(reinterpret_cast<bf16x8*>(Ct + off), o);
+                    if (g.colstat) {      // sums of the values AS STORED, per thread: its 8 columns over the rows it stores
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float x = (float)o[r];
+                            cs1[r] += x;
+                            cs2[r] += x * x;
+                        }
+                    }
+                }
+            }
+            if (CS_OK && g.colstat) {
+                // GroupNorm statistics (pdmk.h, colstat): the 64 rows of a pass belong to one image (rows_per_b % 64 == 0, whole
+                // tiles); the per-thread sums run on over the passes of that image and are flushed when the image changes or the
+                // tile ends: the RS threads of a chunk are added through the staging image, the workgroups by fp32 atomics
+                const int mp0 = row_of(pass * 64);
+                const int img = mp0 / g.rows_per_b;
+                const bool flush = pass == BM / 64 - 1 || row_of((pass + 1) * 64) >= g.M || row_of((pass + 1) * 64) / g.rows_per_b != img;
+                if (flush && mp0 < g.M) {
+                    __syncthreads();
+                    if (tid < CS_STRIDE) {
+                        float* d = stage + (tid / C8) * (2 * BN) + (tid % C8) * 8;
+                        *reinterpret_cast<f32x4*>(d) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
+                        *reinterpret_cast<f32x4*>(d + 4) = f32x4{cs1[4], cs1[5], cs1[6], cs1[7]};
+                        *reinterpret_cast<f32x4*>(d + BN) = f32x4{cs2[0], cs2[1], cs2[2], cs2[3]};
+                        *reinterpret_cast<f32x4*>(d + BN + 4) = f32x4{cs2[4], cs2[5], cs2[6], cs2[7]};
+                    }
+                    __syncthreads();
+                    for (int c = tid; c < 2 * BN; c += NT) {
+                        const int col = c < BN ? c : c - BN;
+                        if (n0 + col >= g.N) continue;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int r = 0; r < RS; ++r) sum += stage[r * (2 * BN) + c];
+                        unsafeAtomicAdd(g.colstat + (long)img * 2 * g.cs_ld + (c < BN ? 0 : g.cs_ld) + g.cs_col0 + n0 + col, sum);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) cs1[r] = cs2[r] = 0.f;
                 }
             }
         } else {

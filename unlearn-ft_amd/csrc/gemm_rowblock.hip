@@ -516,6 +516,7 @@ int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_by
     if (g.bias && (long)ntn * bn > 4096) return 1;
     const bool geglu = g.epilogue == PDMK_EPI_GEGLU;
     if (g.epilogue != PDMK_EPI_NONE && !geglu) return 1;
+    if (g.colstat) return 1;                             // GroupNorm statistics epilogue: ring / halo kernels only
     if (geglu && ((g.N % 16) || g.R || g.accumulate || (g.C2 && (g.ldc2 % 8)))) return 1;
     const long c_bytes = ((long)(g.M - 1) * g.ldc + (geglu ? g.N / 2 : g.N)) * 2;
     const long r_bytes = g.R ? ((long)(g.M - 1) * g.ldr + g.N) * 2 : 0;

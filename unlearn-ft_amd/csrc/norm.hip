@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                                                       const float* __restrict__ part, int nblk,
                                                       float* __restrict__ stats, int HW,
                                                       int C, int ldx, int ldy, int G, int gs, float eps, int silu,
-                                                      int rows_per_blk) {
+                                                      int rows_per_blk, int cs_ld = 0) {
     constexpr int V = Vec<T>::N;
     const int nchunks = C / V;
     const GnMap2 mp = gn_map2(nchunks);
@@ -192,7 +192,23 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
     __shared__ double scr[2][NT], d0[64], d1[64];
     __shared__ float lm[64], lr[64];
-    gn_sum_slabs(part, b, nblk, G, d0, d1, scr);
+    if (nblk < 0) {
+        // statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): `part` = this tensor's first column of the
+        // [B][2][cs_ld] per-(image, column) sums; group g = its gs columns, summed in double
+        if (tid < G) {
+            const float* c0 = part + (long)b * 2 * cs_ld + tid * gs;
+            double a0 = 0.0, a1 = 0.0;
+            for (int j = 0; j < gs; ++j) {
+                a0 += (double)c0[j];
+                a1 += (double)c0[cs_ld + j];
+            }
+            d0[tid] = a0;
+            d1[tid] = a1;
+        }
+        __syncthreads();
+    } else {
+        gn_sum_slabs(part, b, nblk, G, d0, d1, scr);
+    }
     if (tid < G) {
         const double n = (double)HW * gs;
         const double mean = d0[tid] / n;
@@ -698,6 +714,38 @@ int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
 }
 
 }  // namespace
+
+template <typename T>
+int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats, const float* colstat, int cs_ld,
+                     int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps, int silu, hipStream_t st) {
+    constexpr int V = Vec<T>::N;
+    if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
+    const GnMap2 mp = gn_map2(C / V);
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif * 4, 1024, 1 << 20);
+    dim3 grid((HW + rpb - 1) / rpb, B);
+    const int slots = (C / V + NT - 1) / NT;
+#define PDMK_GNA(S)                                                                                                   \
+    hipLaunchKernelGGL((gn_apply_kernel<T, 4, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, colstat, -1, stats, \
+                       HW, C, ldx, ldy, G, gs, eps, silu, rpb, cs_ld)
+    if (slots == 1) PDMK_GNA(1);
+    else if (slots == 2) PDMK_GNA(2);
+    else PDMK_GNA(3);
+#undef PDMK_GNA
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats,
+                                            const float* colstat, int cs_ld, int cs_col0, int B, int HW, int C, int ldx, int ldy,
+                                            int G, int gs, float eps, int silu, int dtype, pdmk_stream stream) {
+    if (!x || !y || !gamma || !beta || !stats || !colstat || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || gs <= 0 || cs_col0 < 0 ||
+        cs_ld < cs_col0 + G * gs)
+        return -1;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == PDMK_BF16) return gn_apply_colstat<bf16>(x, y, gamma, beta, stats, colstat + cs_col0, cs_ld, B, HW, C, ldx, ldy, G, gs, eps, silu, st);
+    if (dtype == PDMK_F32) return gn_apply_colstat<float>(x, y, gamma, beta, stats, colstat + cs_col0, cs_ld, B, HW, C, ldx, ldy, G, gs, eps, silu, st);
+    return -2;
+}
 
 extern "C" int pdmk_groupnorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats,
                                   double* ws, int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps,

@@ -42,7 +42,7 @@ class GemmArgs(C.Structure):
                 ("conv_b", i32), ("conv_hi", i32), ("conv_wi", i32), ("conv_ci", i32), ("conv_ho", i32),
                 ("conv_wo", i32), ("conv_mode", i32), ("conv_ld", i32),
                 ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32), ("ldrv", i32),
-                ("epilogue", i32), ("ldc2", i32), ("C2", vp)]
+                ("epilogue", i32), ("ldc2", i32), ("C2", vp), ("colstat", vp), ("cs_ld", i32), ("cs_col0", i32)]
 
 
 _SIGS = {
@@ -57,6 +57,7 @@ _SIGS = {
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
+    "pdmk_groupnorm_apply_colstat": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd_partial_dims": ([i32, i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
     "pdmk_layernorm_bwd_partial_dims": ([i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
@@ -270,7 +271,7 @@ _GROUP_FNS = {}     # kind -> fn(list of Rec): grouped forms of the non-GEMM for
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
-         macs=None, colsum_out=None, ldrv=0, epilogue=EPI_NONE, C2=None, ldc2=0):
+         macs=None, colsum_out=None, ldrv=0, epilogue=EPI_NONE, C2=None, ldc2=0, colstat=None):
     # accumulate: False / True / 2 (= split-K slabs, see pdmk.h)
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
@@ -286,10 +287,12 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     g.dtype = dt(A) if dtype is None else dtype
     g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
     g.epilogue, g.C2, g.ldc2 = int(epilogue), _p(C2), int(ldc2)
+    if colstat is not None:          # (accumulator [B, 2, cs_ld] fp32, first accumulator column of this output)
+        g.colstat, g.cs_ld, g.cs_col0 = _p(colstat[0]), colstat[0].shape[2], int(colstat[1])
     shape = (M, N, K, int(splitk))
     if RECORD is not None:
         RECORD.append(Rec("gemm", lambda: _launch_gemm(g, macs, shape), g=g, macs=macs,
-                          keep=(A, B, Cout, bias, rowvec, R, colsum_out, C2)))
+                          keep=(A, B, Cout, bias, rowvec, R, colsum_out, C2, colstat)))
         return
     _launch_gemm(g, macs, shape)
 
@@ -447,18 +450,22 @@ def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None, slabs=False):
 
 
 def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
-              a_mode=A_ROWK, conv=None, accumulate=False, macs=None, ldrv=0):
-    """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace."""
+              a_mode=A_ROWK, conv=None, accumulate=False, macs=None, ldrv=0, colstat=None):
+    """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace.
+    colstat: (accumulator, first column) for GroupNorm statistics from the epilogue - the caller checks `colstat_ok` first
+    (unsplit bf16 shapes only).  Returns True when the statistics were accumulated."""
     sk = splitk_plan(A, B, M, N, K, lda, ldb, a_mode, conv)
     if sk == 1:
-        return gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
-                    a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs, ldrv=ldrv)
+        gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
+             a_mode=a_mode, conv=conv, accumulate=accumulate, macs=macs, ldrv=ldrv, colstat=colstat)
+        return colstat is not None
     # split-K: every split stores its fp32 partial into its own slab (plain stores: no atomics, no zero-fill, the sum
     # order is fixed), the finish pass adds the slabs and applies the epilogue
     ws = torch.empty(_ws_bytes(_lib.pdmk_gemm_splitk_workspace_bytes(M, N, sk)) // 4, device=A.device, dtype=torch.float32)
     gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, accumulate=2, macs=macs)
     splitk_finish(ws, Cout, M, N, ldc, sk, bias=bias, rowvec=rowvec, R=R, ldr=ldr, rows_per_b=rows_per_b, ldrv=ldrv,
                   accumulate=accumulate)
+    return False
 
 
 @_recordable("splitk_finish")
@@ -519,6 +526,14 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
         sk = wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode, conv)
     gemm(dy, x, dW, M, N, K, lda, ldb, N, a_mode=A_COLK, b_mode=b_mode, conv=conv, out_f32=True, splitk=sk,
          accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
+
+
+@_recordable("groupnorm_apply_colstat")
+def groupnorm_apply_colstat(x, y, gamma, beta, stats, colstat, col0, B, HW, Cc, ldx, ldy, G, gs, eps, silu):
+    """GroupNorm(+SiLU) forward with the statistics taken from a producing GEMM's epilogue sums (colstat [B, 2, cs_ld])."""
+    _chk(_lib.pdmk_groupnorm_apply_colstat(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), _p(colstat), colstat.shape[2], int(col0),
+                                           B, HW, Cc, ldx, ldy, G, gs, eps, int(silu), dt(x), _st()),
+         "pdmk_groupnorm_apply_colstat")
 
 
 @_recordable("groupnorm_fwd")

@@ -22,10 +22,12 @@ class Act:
     pend: a second finished gradient buffer waiting to be added to `g` (the residual branch's, blocks.py:379).  Reading
     `.g` adds it first (one strided accumulate pass); the GroupNorm backward of the same tensor - the usual next writer -
     takes it as an extra addend of its own store instead, so the fan-in normally costs no pass at all."""
-    __slots__ = ("t", "_g", "rg", "pend", "src")
+    __slots__ = ("t", "_g", "rg", "pend", "src", "cs")
 
     def __init__(self, t, rg=True):
         self.t, self._g, self.rg, self.pend = t, None, rg, None
+        self.cs = None       # (accumulator [B, 2, ld], first column, columns covered): per-(image, column) sums of this tensor from
+                             # its producers' epilogues (pdmk_gemm_args.colstat) - the GroupNorm that reads it skips its statistics pass
         self.src = None      # a GEGLU output: (pre-activation tensor, the projection's Act) - its consumer's input gradient can be
                              # pushed through GEGLU's backward in the GEMM epilogue (PDMK_EPI_GEGLU_BWD)
 
@@ -88,6 +90,11 @@ class UNetEngine:
         # upsampler convs as four 2x2 phase convs on the low-resolution image (PDMK_CONV_UP2=0: nearest x2 fused into the
         # 3x3 gather, 2.25 x the multiply-accumulates)
         self.up2 = os.environ.get("PDMK_CONV_UP2", "1") != "0"
+        # GroupNorm statistics from the producing GEMM's epilogue (PDMK_GN_EPI=0: a statistics pass per GroupNorm).  The
+        # per-(image, column) accumulators of one forward pass live in ONE arena zeroed by one launch at its start
+        self.gn_epi = os.environ.get("PDMK_GN_EPI", "1") != "0" and dtype == torch.bfloat16
+        self._cs_arena, self._cs_off, self._cs_need, self._cs_old = None, 0, 0, []
+        self._cs_views, self._cs_cats = {}, {}
 
     # ------------------------------------------------------------------ helpers
     def _empty(self, rows, cols, dtype=None):
@@ -159,7 +166,7 @@ class UNetEngine:
         return max(1, min(512 // max(tiles, 1), nk // 16, 64))   # >= 16 K-steps per split (measured sweet spot)
 
     # ------------------------------------------------------------------ ops
-    def linear(self, x, key, bias=None, residual=None, out_f32=False, out=None, geglu=False):
+    def linear(self, x, key, bias=None, residual=None, out_f32=False, out=None, geglu=False, cs=None):
         """out: optional [M, N] view (any row stride) to write into instead of a fresh tensor (concat buffers).
         geglu: the projection is GEGLU's (blocks.py:44-59; weight rows packed (hidden, gate)-interleaved, params.py): returns
         hidden * gelu(gate) [M, N/2], computed in the GEMM's epilogue where the library has the fused kernel (bf16 ring
@@ -193,16 +200,22 @@ class UNetEngine:
         elif skinny:
             k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, _ld(y), bias=P.p(bias) if bias else None)
         else:
-            (k.gemm if out_f32 else k.gemm_auto)(
+            # cs = (B, rows per image): a GroupNorm reads this output next - its statistics come out of this epilogue
+            acc = self._cs_for(y, cs[0], cs[1], M, Np, view=out is not None) if (cs is not None and not out_f32) else None
+            got = (k.gemm if out_f32 else k.gemm_auto)(
                 x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, _ld(y), bias=P.p(bias) if bias else None,
                 R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
-                macs=M * e.logical[0] * e.logical[1], **({"out_f32": True} if out_f32 else {}))
+                macs=M * e.logical[0] * e.logical[1],
+                **({"out_f32": True} if out_f32 else ({"colstat": acc, "rows_per_b": cs[1]} if acc is not None else {})))
+            acc_ok = acc is not None and bool(got)
         lmacs = M * e.logical[0] * e.logical[1]
         if self.count_macs:
             self.macs += lmacs
         if geglu and not fused:
             k.geglu_fwd(y, gl, M, Np // 2, _ld(y), Np // 2, layout=1)
         out = Act(y)
+        if cs is not None and not (geglu or skinny) and locals().get("acc_ok"):
+            out.cs = (acc[0], acc[1], Np)
         if self.train:
             def bwd():
                 dy = out.g
@@ -261,7 +274,7 @@ class UNetEngine:
             return act
         return out
 
-    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None, out=None):
+    def conv3(self, x, key, B, Hi, Wi, mode, bias, rowvec=None, residual=None, rv_cols=None, out=None, cs=False):
         """3x3 conv, pad 1.  mode 0: stride 1; 1: stride 2; 2: nearest-x2 upsample fused into the gather; 4: stride 2
         padded on the bottom/right only (VAE encoder downsample; forward only).
         rowvec (+ rv_cols = (first column, width)): per-image row added to every pixel = this ResBlock's column slice of
@@ -277,17 +290,20 @@ class UNetEngine:
         assert tuple(y.shape) == (M, Cop)
         if (mode == 2 and getattr(self, 'up2', False) and rowvec is None and residual is None and
                 k.conv_up2_supported(B, Hi, Wi, Cip, Cop, self.dtype)):
-            return self._conv_up2(x, key, B, Hi, Wi, bias, y, e), Ho, Wo
-        k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
+            return self._conv_up2(x, key, B, Hi, Wi, bias, y, e, ((True if out is not None else None) if cs else False)), Ho, Wo
+        acc = self._cs_for(y, B, Ho * Wo, M, Cop, view=out is not None) if cs else None   # a GroupNorm reads this output next
+        acc_ok = k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
                rowvec=rowvec.t[:, rv_cols[0]:] if rowvec is not None else None, rows_per_b=Ho * Wo,
                ldrv=_ld(rowvec.t) if rowvec is not None else 0,
                R=residual.t if residual else None, ldr=_ld(residual.t) if residual else 0,
-               macs=M * e.logical[0] * e.logical[1] * 9)
+               macs=M * e.logical[0] * e.logical[1] * 9, colstat=acc)
         lmacs = M * e.logical[0] * e.logical[1] * 9
         if self.count_macs:
             self.macs += lmacs
         out = Act(y)
+        if acc is not None and acc_ok:
+            out.cs = (acc[0], acc[1], Cop)
         if self.train:
             def bwd():
                 dy = out.g
@@ -328,7 +344,7 @@ class UNetEngine:
             self.tape.append(bwd)
         return out, Ho, Wo
 
-    def _conv_up2(self, x, key, B, Hi, Wi, bias, y, e):
+    def _conv_up2(self, x, key, B, Hi, Wi, bias, y, e, cs=False):
         """Upsample2D (nearest x2 + 3x3 conv; unet_2d_conditional.py up blocks) as four 2x2 phase convs
         on the low-resolution image (pdmk.h conv_mode 5..12): 16 instead of 36 multiply-accumulates per low-resolution pixel,
         forward, input gradient and weight gradient alike.  The four phases of the forward and of the weight gradient are
@@ -339,14 +355,19 @@ class UNetEngine:
         wp, wpt = P.up2_weights(key)
         lmacs = 4 * Ml * e.logical[0] * e.logical[1] * 4           # executed multiply-accumulates (the 3x3 form: 9 / 4 of it)
         geo = lambda m, ci, ld: (B, Hi, Wi, ci, Hi, Wi, m, ld)
+        # cs: None = y is a fresh tensor, True = a concat view (the four phases add their column sums to that buffer's
+        # GroupNorm accumulator; rows are counted on the low-resolution grid each phase enumerates)
+        acc = self._cs_for(y, B, Hi * Wi, Ml, Cop, view=cs is True) if cs is not False else None
         with k.Recorder() as r:
             for p_ in range(4):
                 k.gemm(x.t, wp[p_], y, Ml, Cop, 4 * Cip, 0, 4 * Cip, _ld(y), a_mode=k.A_CONV, conv=geo(5 + p_, Cip, _ld(x.t)),
-                       bias=P.p(bias), macs=lmacs // 4)
+                       bias=P.p(bias), macs=lmacs // 4, colstat=acc, rows_per_b=Hi * Wi if acc is not None else 0)
         self._issue(r.recs)
         if self.count_macs:
             self.macs += 4 * Ml * e.logical[0] * e.logical[1] * 9  # model MACs are counted as the reference executes them
         out = Act(y)
+        if acc is not None:
+            out.cs = (acc[0], acc[1], Cop)
         if self.train:
             def bwd():
                 dy = out.g
@@ -395,6 +416,51 @@ class UNetEngine:
         else:
             k.gemm_group(recs)
 
+    def _cs_begin(self):
+        """Start of a forward pass: one zero fill for every GroupNorm accumulator of the pass."""
+        self.gn_count = [0, 0]
+        if not self.gn_epi:
+            return
+        if self._cs_need and (self._cs_arena is None or self._cs_arena.numel() < self._cs_need):
+            # grow: the old arena is RETAINED - a captured graph of an earlier (smaller) pass still zeroes and adds into it
+            self._cs_old.append(self._cs_arena)
+            self._cs_arena = torch.empty(max(self._cs_need, 1 << 16), device=self.dev, dtype=torch.float32)
+        self._cs_off, self._cs_need = 0, 0
+        self._cs_views, self._cs_cats = {}, {}
+        self.gn_count = [0, 0]          # GroupNorms of this pass, of which with statistics from a producer's epilogue
+        if self._cs_arena is not None:
+            k.zero_(self._cs_arena)
+
+    def _cs_alloc(self, B, cols):
+        """Zeroed accumulator [B, 2, cols] (a slice of the pass's arena; the first pass of a new shape sizes the arena and
+        zeroes its accumulators one by one)."""
+        n = B * 2 * cols
+        n = (n + 3) & ~3
+        self._cs_need += n
+        if self._cs_arena is not None and self._cs_off + n <= self._cs_arena.numel():
+            t = self._cs_arena[self._cs_off:self._cs_off + B * 2 * cols].view(B, 2, cols)
+            self._cs_off += n
+            return t
+        return k.zeros((B, 2, cols), self.dev, torch.float32)
+
+    @staticmethod
+    def _cs_shape_ok(M, B, ld):
+        return B > 0 and M % B == 0 and (M // B) % 64 == 0 and ld % 8 == 0
+
+    def _cs_for(self, y, B, rows_per_b, M, N, view=False):
+        """(accumulator [B, 2, ld], first column) for a GEMM that writes `y` [M, N] and whose output a GroupNorm reads next -
+        or None when the statistics epilogue cannot take the shape (the GroupNorm then runs its own statistics pass).
+        view: y is a concat-buffer view handed out by _skip_view / _left_view - the sums go to that buffer's accumulator, at the
+        view's columns, so that the GroupNorm over the whole concat finds both halves in one place."""
+        if not (self.gn_epi and rows_per_b > 0 and rows_per_b % 64 == 0 and M % 64 == 0 and N % 8 == 0 and
+                y.stride(0) % 8 == 0 and y.dtype == torch.bfloat16):
+            return None
+        if view:
+            ent = self._cs_views.get(y.data_ptr())
+            if ent is not None and ent[0].shape[0] == B and ent[1] + N <= ent[0].shape[2]:
+                return ent
+        return self._cs_alloc(B, N), 0
+
     def groupnorm(self, x, key, B, HW, G, gs, eps, silu):
         P = self.P
         k.TAG = key
@@ -402,8 +468,14 @@ class UNetEngine:
         y = self._empty(B * HW, C)
         stats = torch.empty((B, G, 2), device=self.dev, dtype=torch.float32)
         gw, gb = P.p(key + ".weight"), P.p(key + ".bias")
-        self.ws = k.groupnorm_ws(self.dev, B, G, self.ws)
-        k.groupnorm_fwd(x.t, y, gw, gb, stats, self.ws, B, HW, C, _ld(x.t), C, G, gs, eps, silu)
+        cs = x.cs
+        self.gn_count[0] += 1
+        if cs is not None and cs[2] >= G * gs and cs[0].shape[0] == B:
+            self.gn_count[1] += 1
+            k.groupnorm_apply_colstat(x.t, y, gw, gb, stats, cs[0], cs[1], B, HW, C, _ld(x.t), C, G, gs, eps, silu)
+        else:
+            self.ws = k.groupnorm_ws(self.dev, B, G, self.ws)
+            k.groupnorm_fwd(x.t, y, gw, gb, stats, self.ws, B, HW, C, _ld(x.t), C, G, gs, eps, silu)
         out = Act(y)
         if self.train:
             def bwd():
@@ -497,12 +569,18 @@ class UNetEngine:
         M, Ca, Cb = a.t.shape[0], a.t.shape[1], b.t.shape[1]
         if cat is not None and tuple(cat.shape) != (M, Ca + Cb):
             cat = None
+        inplace = cat is not None
         if cat is None:
             cat = self._empty(M, Ca + Cb)
             k.copy2d(b.t, cat[:, Ca:], M, Cb, _ld(b.t), Ca + Cb)
         if not (a.t.data_ptr() == cat.data_ptr() and _ld(a.t) == Ca + Cb):
             k.copy2d(a.t, cat, M, Ca, _ld(a.t), Ca + Cb)
+            inplace = False
         out = Act(cat)
+        acc = self._cs_cats.get(cat.data_ptr()) if inplace else None
+        if (acc is not None and a.cs is not None and b.cs is not None and a.cs[0].data_ptr() == acc.data_ptr() and
+                b.cs[0].data_ptr() == acc.data_ptr() and a.cs[1:] == (0, Ca) and b.cs[1:] == (Ca, Cb)):
+            out.cs = (acc, 0, Ca + Cb)        # both producers summed into this buffer's accumulator: norm1 has its statistics
         if self.train:
             def bwd():
                 self._give(a, out.g[:, :Ca])
@@ -510,13 +588,21 @@ class UNetEngine:
             self.tape.append(bwd)
         return out
 
-    def _skip_view(self, k_, M, C):
-        """(buffer, view) for the producer of skip number k_ (push order): the right C columns of its concat buffer."""
+    def _skip_view(self, k_, M, C, B=0):
+        """(buffer, view) for the producer of skip number k_ (push order): the right C columns of its concat buffer.  The
+        buffer gets ONE GroupNorm accumulator for all its columns (both producers add their column sums to it)."""
         ch = self.cat_ch[k_] if k_ < len(self.cat_ch) else None
         if ch is None:
             return None, None
         cat = self._empty(M, ch + C)
-        return cat, cat[:, ch:]
+        view = cat[:, ch:]
+        if self.gn_epi and self._cs_shape_ok(M, B, ch + C) and self.dtype == torch.bfloat16:
+            acc = self._cs_alloc(B, ch + C)
+            self._cs_cats[cat.data_ptr()] = acc
+            self._cs_views[view.data_ptr()] = (acc, ch)
+            if ch:
+                self._cs_views[cat.data_ptr()] = (acc, 0)
+        return cat, view
 
     @staticmethod
     def _left_view(skips, M, C):
@@ -541,18 +627,19 @@ class UNetEngine:
                     self.grad_ready_cb(off)
             self.tape.append(mark)
 
-    def resblock(self, x, r, st, B, H, W, out=None):
+    def resblock(self, x, r, st, B, H, W, out=None, cs=True):
+        """cs: a GroupNorm reads this block's output directly (not through a concat): conv2's epilogue forms its statistics."""
         G = self.cfg.norm_num_groups
         p = r.name
         self._mark(p + ".norm1.weight")
         n1 = self.groupnorm(x, p + ".norm1", B, H * W, G, r.cin // G, 1e-5, True)
-        h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=st, rv_cols=self.temb_lay[p][:2])
+        h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=st, rv_cols=self.temb_lay[p][:2], cs=True)
         n2 = self.groupnorm(h1, p + ".norm2", B, H * W, r.groups2(G), r.cout // G, 1e-5, True)
         res = x if r.cin == r.cout else self.linear(x, p + ".conv_shortcut", bias=p + ".conv_shortcut.bias")
-        y, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res, out=out)
+        y, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res, out=out, cs=cs)
         return y
 
-    def transformer(self, x, a, ehs, B, H, W, T, out=None):
+    def transformer(self, x, a, ehs, B, H, W, T, out=None, cs=True):
         G = self.cfg.norm_num_groups
         p, c, N = a.name, a.c, H * W
         t = p + ".transformer_blocks.0"
@@ -574,7 +661,7 @@ class UNetEngine:
         l3 = self.layernorm(h, t + ".norm3")
         gl = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True)
         h = self.linear(gl, t + ".ff.net.2", bias=t + ".ff.net.2.bias", residual=h)
-        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out)
+        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out, cs=(B, N) if cs else None)
 
     # ------------------------------------------------------------------ whole model
     def forward(self, x, timesteps, ehs, B, H, W, train):
@@ -583,6 +670,7 @@ class UNetEngine:
         cfg = self.cfg
         self.train = train
         self.tape = []
+        self._cs_begin()
         T = ehs.shape[0] // B
         c0 = cfg.block_out_channels[0]
         k.TAG = "time_embedding"
@@ -606,8 +694,8 @@ class UNetEngine:
             nskip += 1
 
         skips = []
-        cat, view = self._skip_view(nskip, B * H * W, c0p)
-        h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias", out=view)
+        cat, view = self._skip_view(nskip, B * H * W, c0p, B)
+        h, _, _ = self.conv3(Act(x, rg=False), "conv_in", B, H, W, 0, "conv_in.bias", out=view, cs=True)
         push(h, cat)
         acts = {}
         for b in self.blocks:
@@ -615,7 +703,7 @@ class UNetEngine:
             if b.kind == "down":
                 for j, r in enumerate(b.resnets):
                     att = b.attns[j] if (b.attns and not b.attns[j].dropped) else None
-                    cat, view = self._skip_view(nskip, B * H * W, cb)
+                    cat, view = self._skip_view(nskip, B * H * W, cb, B)
                     made = False
                     if not r.dropped:
                         h = self.resblock(h, r, st, B, H, W, out=None if att is not None else view)
@@ -626,9 +714,9 @@ class UNetEngine:
                     # both layers dropped: the skip IS the previous tensor, which has no concat buffer for this consumer
                     push(h, cat if made else None)
                 if b.sampler:
-                    cat, view = self._skip_view(nskip, B * ((H + 1) // 2) * ((W + 1) // 2), cb)
+                    cat, view = self._skip_view(nskip, B * ((H + 1) // 2) * ((W + 1) // 2), cb, B)
                     h, H, W = self.conv3(h, f"{b.name}.downsamplers.0.conv", B, H, W, 1,
-                                         f"{b.name}.downsamplers.0.conv.bias", out=view)
+                                         f"{b.name}.downsamplers.0.conv.bias", out=view, cs=True)
                     push(h, cat)
                 acts[f"d{b.idx}"] = h
             elif b.kind == "mid":
@@ -643,14 +731,17 @@ class UNetEngine:
                     att = b.attns[j] if (b.attns and not b.attns[j].dropped) else None
                     # the tensor this pair leaves behind is the left half of the next concat (unless an upsampler follows)
                     nxt = None if (j == n - 1 and b.sampler) else self._left_view(skips, B * H * W, cb)
+                    # (ahead of an upsampler no GroupNorm reads the tensor: no statistics for it)
+                    last = j == n - 1 and b.sampler
                     if not r.dropped:      # dropped: keep the non-skip channels == h itself (blocks.py:502-515)
-                        h = self.resblock(self.concat(h, s, scat), r, st, B, H, W, out=None if att is not None else nxt)
+                        h = self.resblock(self.concat(h, s, scat), r, st, B, H, W, out=None if att is not None else nxt,
+                                          cs=att is not None or not last)
                     if att is not None:
-                        h = self.transformer(h, att, ehs_act, B, H, W, T, out=nxt)
+                        h = self.transformer(h, att, ehs_act, B, H, W, T, out=nxt, cs=not last)
                 if b.sampler:
                     h, H, W = self.conv3(h, f"{b.name}.upsamplers.0.conv", B, H, W, 2,
                                          f"{b.name}.upsamplers.0.conv.bias",
-                                         out=self._left_view(skips, B * 4 * H * W, cb))
+                                         out=self._left_view(skips, B * 4 * H * W, cb), cs=True)
                 acts[f"u{b.idx}"] = h
         assert not skips
         n = self.groupnorm(h, "conv_norm_out", B, H * W, cfg.norm_num_groups, c0 // cfg.norm_num_groups, 1e-5, True)
