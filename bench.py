@@ -368,6 +368,8 @@ def main():
         extras["gemm_launches_main_step"] = len(prof)
         gc = student.engine.gn_count          # GroupNorms of the student's last forward pass / with statistics from a GEMM epilogue
         extras["groupnorms_per_forward"], extras["groupnorm_stats_from_gemm_epilogue"] = gc[0], gc[1]
+        if student.engine.gn_miss is not None:
+            extras["groupnorm_without_epilogue_stats"] = {"student": student.engine.gn_miss, "teacher": teacher.engine.gn_miss}
         extras["gemm_problems_in_grouped_launches"] = sum(kd[4] for kd, *_ in prof if len(kd) > 4 and kd[4] > 1)
         agg, cls = {}, {}
         for kind, flops, e0, e1, shp in prof:

@@ -168,6 +168,12 @@ int pdmk_gemm_candidate_name(int a_mode, int b_mode, int id, char* buf, int n);
 int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
                        int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int nslab /* slabs in ws */,
                        int accumulate, int dtype, pdmk_stream stream);
+/* pdmk_splitk_finish that also adds the GroupNorm statistics of the stored output to `colstat` (as pdmk_gemm_args.colstat does
+ * for an unsplit producer: [B][2][cs_ld] fp32 sums / sums of squares per (image, column), fp32 atomics, first column cs_col0).
+ * M % 64 == 0 and rows_per_b % 64 == 0 (rows of one image per 64-row block), else -1. */
+int pdmk_splitk_finish_colstat(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
+                               int N, int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int accumulate, float* colstat,
+                               int cs_ld, int cs_col0, int dtype, pdmk_stream stream);
 /* Bytes of the fp32 slab workspace of a split-K forward / dgrad GEMM ([splitk][M][N]); -1 on bad arguments. */
 /* Weight gradients (a_mode = PDMK_A_COLK) also take accumulate = 2: split z then stores its partial dW into slab z of a
  * [splitk][M][N] fp32 workspace (ldc = N) instead of adding into the gradient with float atomics (~1.3 TB/s chip-wide: for

@@ -1195,6 +1195,20 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         k.groupnorm_apply_colstat(y, z1, gamma, beta, st1, acc, 0, Bn, rows, Co, Co, Co, G, gs, 1e-5, True)
         close(st1, st0, 1e-4, "statistics from the epilogue vs the statistics pass")
         close(z1, z0, 1e-2, "groupnorm from epilogue statistics")
+    # split-K producers: the statistics leave with the finish pass (pdmk_splitk_finish_colstat), slabs and ragged columns
+    for Bn, rows, N, K, sk in ((2, 64, 1280, 640, 3), (4, 256, 328, 320, 2)):
+        M = Bn * rows
+        a, w, bias = rnd((M, K), dev, dt), rnd((N, K), dev, dt, K ** -0.5), torch.randn(N, device=dev)
+        res, rv = rnd((M, N), dev, dt), torch.randn(Bn, N, device=dev)
+        ws = torch.zeros(sk, M, N, device=dev)
+        k.gemm(a, w, ws, M, N, K, K, K, N, out_f32=True, splitk=sk, accumulate=2)
+        y0, y1 = torch.zeros(M, N, device=dev, dtype=dt), torch.zeros(M, N + 8, device=dev, dtype=dt)[:, :N]
+        acc = torch.zeros(Bn, 2, N + 8, device=dev)
+        k.splitk_finish(ws, y0, M, N, N, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows)
+        k.splitk_finish(ws, y1, M, N, N + 8, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows, colstat=(acc, 8))
+        assert torch.equal(y0, y1)
+        check(acc, 8, y1, Bn, rows, f"split-K finish B{Bn} rows{rows} N{N}")
+        assert (acc[:, :, :8] == 0).all()
     # shapes the epilogue does not take are refused (-1), never silently skipped
     y = torch.zeros(96, 64, device=dev, dtype=dt)
     with pytest.raises(k.PdmkError):

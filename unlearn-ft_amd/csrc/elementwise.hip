@@ -519,6 +519,72 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
     }
 }
 
+// The same finish with the GroupNorm statistics of the stored output (pdmk_gemm_args.colstat, for split-K producers): a block
+// owns 64 rows of one image x 64 columns; thread = (row % 16, 4-column chunk), four sweeps; the per-thread column sums of the
+// values AS STORED are added over the 16 row-threads through LDS and leave as fp32 atomics into colstat[image][0 / 1][column].
+template <typename T>
+__global__ __launch_bounds__(NT) void splitk_finish_cs_kernel(const float* __restrict__ ws, T* __restrict__ C, const float* __restrict__ bias,
+                                                              const float* __restrict__ rowvec, const T* __restrict__ R, long M, int N,
+                                                              int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int acc,
+                                                              float* __restrict__ colstat, int cs_ld) {
+    static_assert(NT == 256, "16 row-threads x 16 column chunks");
+    __shared__ float part[16][2][64];
+    const int tid = threadIdx.x, cc = tid & 15, rr = tid >> 4;
+    const long m0 = (long)blockIdx.x * 64;
+    const int n = blockIdx.y * 64 + cc * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+            const long m = m0 + sw * 16 + rr;
+            if (m >= M) break;
+            float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
+            for (int sl = 1; sl < nslab; ++sl) {
+                const float4 u = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * N + n);
+                w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
+            }
+            float v[4] = {w.x, w.y, w.z, w.w};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
+            }
+            if (rowvec) {
+                const float* rv = rowvec + (m / rows_per_b) * ldrv + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += rv[e];
+            }
+            if (R) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += to_f32(R[m * ldr + n + e]);
+            }
+            T* c = C + m * ldc + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const T o = from_f32<T>(v[e] + (acc ? to_f32(c[e]) : 0.f));
+                c[e] = o;
+                const float x = to_f32(o);
+                s1[e] += x;
+                s2[e] += x * x;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        part[rr][0][cc * 4 + e] = s1[e];
+        part[rr][1][cc * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, col = tid & 63, nn = blockIdx.y * 64 + col;
+        if (nn < N && m0 < M) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += part[r][which][col];
+            unsafeAtomicAdd(colstat + (m0 / rows_per_b) * 2 * cs_ld + (long)which * cs_ld + nn, sum);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ upsampling conv as 4 phases
 // nearest-x2 upsample + 3x3 conv == four 2x2 convs on the low-resolution image (conv_mode 5..12, gemm_ring.hip): the 3x3 taps
 // that fall on the same source pixel are summed.  For output phase a (row parity) source row offset dy in {0, 1} collects
@@ -839,6 +905,24 @@ extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, c
     else if (dtype == PDMK_F32)
         hipLaunchKernelGGL(splitk_finish_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
                            (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate);
+    else return -2;
+    PDMK_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int pdmk_splitk_finish_colstat(const float* ws, void* C, const float* bias, const float* rowvec, const void* R,
+                                          int64_t M, int N, int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int accumulate,
+                                          float* colstat, int cs_ld, int cs_col0, int dtype, pdmk_stream s) {
+    if (!ws || !C || !colstat || M <= 0 || N <= 0 || (N & 3) || rows_per_b <= 0 || (rows_per_b % 64) || (M % 64) || nslab < 1 ||
+        cs_col0 < 0 || cs_ld < cs_col0 + N)
+        return -1;
+    if (ldrv <= 0) ldrv = N;
+    dim3 grid((unsigned)(M / 64), (unsigned)((N + 63) / 64));
+    if (dtype == PDMK_BF16)
+        hipLaunchKernelGGL(splitk_finish_cs_kernel<bf16>, grid, dim3(NT), 0, (hipStream_t)s, ws, (bf16*)C, bias, rowvec,
+                           (const bf16*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate, colstat + cs_col0, cs_ld);
+    else if (dtype == PDMK_F32)
+        hipLaunchKernelGGL(splitk_finish_cs_kernel<float>, grid, dim3(NT), 0, (hipStream_t)s, ws, (float*)C, bias, rowvec,
+                           (const float*)R, (long)M, N, ldc, ldr, rows_per_b, ldrv, nslab, accumulate, colstat + cs_col0, cs_ld);
     else return -2;
     PDMK_CHECK_LAUNCH();
     return 0;

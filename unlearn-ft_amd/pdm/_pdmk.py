@@ -56,6 +56,7 @@ _SIGS = {
     "pdmk_gemm_last_candidate": ([], i32),
     "pdmk_gemm_candidate_name": ([i32, i32, i32, C.c_char_p, i32], i32),
     "pdmk_splitk_finish": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_splitk_finish_colstat": ([vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp], i32),
     "pdmk_groupnorm_fwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_apply_colstat": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp], i32),
     "pdmk_groupnorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], i32),
@@ -452,8 +453,8 @@ def wgrad_plan(dy, x, M, N, K, lda, ldb, b_mode=B_COLK, conv=None, slabs=False):
 def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
               a_mode=A_ROWK, conv=None, accumulate=False, macs=None, ldrv=0, colstat=None):
     """Forward / dgrad GEMM with the split-K decision made by the planner: split shapes go through an fp32 workspace.
-    colstat: (accumulator, first column) for GroupNorm statistics from the epilogue - the caller checks `colstat_ok` first
-    (unsplit bf16 shapes only).  Returns True when the statistics were accumulated."""
+    colstat: (accumulator, first column): GroupNorm statistics of the stored output from the GEMM's epilogue, or from the finish
+    pass of a split plan (M % 64 == 0 and rows_per_b % 64 == 0, bf16).  Returns True when the statistics were accumulated."""
     sk = splitk_plan(A, B, M, N, K, lda, ldb, a_mode, conv)
     if sk == 1:
         gemm(A, B, Cout, M, N, K, lda, ldb, ldc, bias=bias, rowvec=rowvec, rows_per_b=rows_per_b, R=R, ldr=ldr,
@@ -464,13 +465,19 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
     ws = torch.empty(_ws_bytes(_lib.pdmk_gemm_splitk_workspace_bytes(M, N, sk)) // 4, device=A.device, dtype=torch.float32)
     gemm(A, B, ws, M, N, K, lda, ldb, N, a_mode=a_mode, conv=conv, out_f32=True, splitk=sk, accumulate=2, macs=macs)
     splitk_finish(ws, Cout, M, N, ldc, sk, bias=bias, rowvec=rowvec, R=R, ldr=ldr, rows_per_b=rows_per_b, ldrv=ldrv,
-                  accumulate=accumulate)
-    return False
+                  accumulate=accumulate, colstat=colstat)
+    return colstat is not None
 
 
 @_recordable("splitk_finish")
 def splitk_finish(ws, Cout, M, N, ldc, nslab, *, bias=None, rowvec=None, R=None, ldr=0, rows_per_b=0, ldrv=0,
-                  accumulate=False):
+                  accumulate=False, colstat=None):
+    """colstat = (accumulator [B, 2, ld], first column): the GroupNorm statistics of the stored output leave with this pass."""
+    if colstat is not None:
+        _chk(_lib.pdmk_splitk_finish_colstat(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv,
+                                             nslab, int(accumulate), _p(colstat[0]), colstat[0].shape[2], int(colstat[1]),
+                                             dt(Cout), _st()), "pdmk_splitk_finish_colstat")
+        return
     _chk(_lib.pdmk_splitk_finish(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv, nslab,
                                  int(accumulate), dt(Cout), _st()), "pdmk_splitk_finish")
 

@@ -419,6 +419,7 @@ class UNetEngine:
     def _cs_begin(self):
         """Start of a forward pass: one zero fill for every GroupNorm accumulator of the pass."""
         self.gn_count = [0, 0]
+        self.gn_miss = [] if os.environ.get("PDMK_GN_EPI_DEBUG") else None    # (layer, rows, columns) of GroupNorms without them
         if not self.gn_epi:
             return
         if self._cs_need and (self._cs_arena is None or self._cs_arena.numel() < self._cs_need):
@@ -470,6 +471,8 @@ class UNetEngine:
         gw, gb = P.p(key + ".weight"), P.p(key + ".bias")
         cs = x.cs
         self.gn_count[0] += 1
+        if cs is None and self.gn_miss is not None:
+            self.gn_miss.append((key, B * HW, C))
         if cs is not None and cs[2] >= G * gs and cs[0].shape[0] == B:
             self.gn_count[1] += 1
             k.groupnorm_apply_colstat(x.t, y, gw, gb, stats, cs[0], cs[1], B, HW, C, _ld(x.t), C, G, gs, eps, silu)
