@@ -46,4 +46,11 @@ for B, H, Nq, Nk in [(8, 5, 4096, 4096), (8, 2, 4096, 4096), (16, 5, 4096, 4096)
         tf = gtime(lambda: k.attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, D ** -0.5))
         tb = gtime(lambda: k.attn_bwd(q, kk, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_, os_, (Nk * H * D, H * D), (Nk * H * D, H * D), D ** -0.5))
         row.append(f"NQ{nq}: fwd {tf:7.1f} us {fl / tf / 1e6:6.1f} TF/s | bwd {tb:7.1f} us {2.5 * fl / tb / 1e6:6.1f} TF/s")
+    os.environ.pop("PDMK_ATTN_NQ")
+    for a_, b_ in (("1", "2"), ("2", "1"), ("0", "0")):         # dQ / dK,dV forms mixed; 0 = the library's own choice
+        os.environ["PDMK_ATTN_NQ_DQ"], os.environ["PDMK_ATTN_NQ_DKV"] = a_, b_
+        tb = gtime(lambda: k.attn_bwd(q, kk, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, qs, ks, vs, os_, os_, (Nk * H * D, H * D), (Nk * H * D, H * D), D ** -0.5))
+        row.append(f"dq{a_}/dkv{b_}: bwd {tb:7.1f} us")
+    tf = gtime(lambda: k.attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, qs, ks, vs, os_, D ** -0.5))
+    row.append(f"default fwd {tf:7.1f} us")
     print(f"B{B} H{H} Nq{Nq} Nk{Nk}: " + "   ".join(row))

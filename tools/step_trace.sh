@@ -11,3 +11,5 @@ cd $R
 DB=$(find /tmp/p_kt_$TAG -name "*results.db" | head -1)
 python tools/rocpd_step.py $DB 5 90 > gpurun_out/${TAG}_step_breakdown.txt 2>&1
 head -5 gpurun_out/${TAG}_step_breakdown.txt
+python tools/rocpd_gaps.py $DB 5 > gpurun_out/${TAG}_gaps.txt 2>&1
+cat gpurun_out/${TAG}_gaps.txt

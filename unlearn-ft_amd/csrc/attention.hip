@@ -24,6 +24,7 @@ constexpr int NT = 256;
 constexpr int D = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 constexpr unsigned OOB = 0x80000000u;
 
 #ifndef PDMK_ATTN_KVB
@@ -194,8 +195,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
         ones = 1.0f;
     }
 
+    // One key block.  TAIL (the last block when Nk is not a multiple of KVB) is the only one that masks keys past the end: it is
+    // a second copy of the body, so that the full blocks carry no mask arithmetic at all (the compiler if-converted the mask of a
+    // single body into ~50 compare / select instructions per block, a quarter of the loop's VALU work, which binds this kernel).
     int cur = 0;
-    for (int kb = 0; kb < Nk; kb += KVB) {
+    auto block = [&](auto tail_c, const int kb) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         const bool more = kb + KVB < Nk;
         if (more) {
             KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
@@ -213,13 +218,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
                 for (int n = 0; n < NQ; ++n) st[n][t] = MM::mma(kf, qf[n][kk], st[n][t]);
             }
         }
-        // softmax on the raw scores (the loop is VALU-bound at d = 64: per score element max, fma, exp2 and half a
-        // convert; the scale rides in the fma, the row sum is an MFMA against a ones fragment, masking only in a tail tile)
-        const bool tail = kb + KVB > Nk;
+        // softmax on the raw scores (the loop is VALU-bound at d = 64: per score element a max, half a packed fma, an exp2 and
+        // half a convert; the scale rides in the fma, the row sum is an MFMA against a ones fragment)
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             float mx = -INFINITY;
-            if (tail) {
+            if (TAIL) {
 #pragma unroll
                 for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -240,19 +244,32 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[n][t][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m_run[n], mx * scale2);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[n] - mn);
-            m_run[n] = mn;
+            // Lazy rescale: the running reference m_run only moves when the block maximum exceeds it by more than 2^8 - then
+            // exp2(s - m_run) <= 256 in every later block (fp32 accumulators, bf16 probabilities: same relative precision), and
+            // O, l and the saved LSE = m_run + log2(l) stay consistent with whatever reference was used.  After the first few
+            // blocks no lane of the wave moves, and the 40 accumulator multiplies + the exp2 of alpha are skipped (wave-uniform)
+            const float mxs = mx * scale2;
+            const bool move = mxs > m_run[n] + 8.0f;              // m_run starts at -inf: the first block always moves
+            if (__builtin_amdgcn_ballot_w64(move)) {
+                const float mn = move ? mxs : m_run[n];
+                const float alpha = __builtin_amdgcn_exp2f(m_run[n] - mn);
+                m_run[n] = mn;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ol[n][r] *= alpha;
+                for (int r = 0; r < 4; ++r) ol[n][r] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ot[n][dt][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) ot[n][dt][r] *= alpha;
+            }
+            const f32x2 sc2 = {scale2, scale2}, nm2 = {-m_run[n], -m_run[n]};
 #pragma unroll
             for (int t = 0; t < NKT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st[n][t][r] = __builtin_amdgcn_exp2f(fmaf(st[n][t][r], scale2, -mn));
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 e2 = __builtin_elementwise_fma(f32x2{st[n][t][r], st[n][t][r + 1]}, sc2, nm2);   // v_pk_fma_f32
+                    st[n][t][r] = __builtin_amdgcn_exp2f(e2[0]);
+                    st[n][t][r + 1] = __builtin_amdgcn_exp2f(e2[1]);
+                }
         }
 #pragma unroll
         for (int pr = 0; pr < NKT / 2; ++pr) {
@@ -278,7 +295,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const T* __restrict__ q, c
         }
         __syncthreads();
         cur ^= 1;
-    }
+    };
+    const int nfull = Nk / KVB * KVB;
+    for (int kb = 0; kb < nfull; kb += KVB) block(std::false_type{}, kb);
+    if (nfull < Nk) block(std::true_type{}, nfull);
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         const float l = ol[n][0];
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     __shared__ __attribute__((aligned(16))) T Vs[KROWS * RS];
     __shared__ __attribute__((aligned(16))) T Qs[2][QB * RS];
     __shared__ __attribute__((aligned(16))) T Os[2][QB * RS];
-    __shared__ float Ls[2][QB], Ds[2][QB];                     // -lse, -delta of the query block
+    __shared__ __attribute__((aligned(16))) float Ls[2][QB], Ds[2][QB];   // -lse, -delta of the query block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kblocks = (Nk + KROWS - 1) / KROWS;
@@ -380,7 +400,6 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
     __syncthreads();
     typename MM::frag kf[NKW][D / MM::KS], vf[NKW][D / MM::KS];  // B operands: B[k = d][col = key]
     f32x4 dkt[NKW][4], dvt[NKW][4];        // dK^T / dV^T [d = dt*16 + 4g + r][key = lane&15]
-    bool kvalid[NKW];
 #pragma unroll
     for (int j = 0; j < NKW; ++j) {
 #pragma unroll
@@ -390,9 +409,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { dkt[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        kvalid[j] = k0 + (wave * NKW + j) * 16 + (lane & 15) < Nk;
     }
-    const bool ktail = k0 + KROWS > Nk;    // only the last key block masks keys
 
     int cur = 0;
     for (int qb = q_begin; qb < q_end; qb += QB) {
@@ -407,9 +424,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
             f32x4 sacc[NKW], dp[NKW];
-            f32x4 nd;                      // dP starts at -delta (dS = P * (dP - delta) without the subtraction)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) nd[r] = Ds[cur][t * 16 + (lane >> 4) * 4 + r];
+            // dP starts at -delta (dS = P * (dP - delta) without the subtraction)
+            const f32x4 nd = *reinterpret_cast<const f32x4*>(&Ds[cur][t * 16 + (lane >> 4) * 4]);
+            const f32x4 nlv = *reinterpret_cast<const f32x4*>(&Ls[cur][t * 16 + (lane >> 4) * 4]);
 #pragma unroll
             for (int j = 0; j < NKW; ++j) { sacc[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = nd; }
 #pragma unroll
@@ -422,15 +439,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
                     dp[j] = MM::mma(oa, vf[j][kk], dp[j]);
                 }
             }
+            // (keys past the end need no mask: their dK / dV columns are never stored; queries past the end have -lse = -inf)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float nl = Ls[cur][t * 16 + (lane >> 4) * 4 + r];
+            for (int r = 0; r < 4; r += 2) {
 #pragma unroll
                 for (int j = 0; j < NKW; ++j) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], scale2, nl));
-                    if (ktail && !kvalid[j]) pv = 0.f;
-                    p[j][t][r] = pv;
-                    ds[j][t][r] = pv * dp[j][r];
+                    const f32x2 e2 = __builtin_elementwise_fma(f32x2{sacc[j][r], sacc[j][r + 1]}, f32x2{scale2, scale2}, f32x2{nlv[r], nlv[r + 1]});
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                    const f32x2 d2 = pv * f32x2{dp[j][r], dp[j][r + 1]};
+                    p[j][t][r] = pv[0];
+                    p[j][t][r + 1] = pv[1];
+                    ds[j][t][r] = d2[0];
+                    ds[j][t][r + 1] = d2[1];
                 }
             }
         }
@@ -580,7 +600,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
             KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
             KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
         }
-        const bool tail = kb + KVB > Nk;
+        // (no mask for keys past the end: their K rows are hardware zero fill, so whatever finite dS they get adds nothing to
+        // dQ = dS K - the select per score element was half of this VALU-bound loop's instructions)
         f32x4 dst[NQ][NKT];                 // dS^T[key = 16t + 4g + r][query]
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -603,10 +624,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
 #pragma unroll
             for (int n = 0; n < NQ; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[n][r], scale2, nl2[n]));
-                    if (tail && kb + t * 16 + (lane >> 4) * 4 + r >= Nk) pv = 0.f;
-                    dst[n][t][r] = pv * dp[n][r];
+                for (int r = 0; r < 4; r += 2) {          // two score elements per v_pk_fma_f32 / v_pk_mul_f32
+                    const f32x2 e2 = __builtin_elementwise_fma(f32x2{s[n][r], s[n][r + 1]}, f32x2{scale2, scale2}, f32x2{nl2[n], nl2[n]});
+                    const f32x2 d2 = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} * f32x2{dp[n][r], dp[n][r + 1]};
+                    dst[n][t][r] = d2[0];
+                    dst[n][t][r + 1] = d2[1];
                 }
         }
 #pragma unroll
@@ -712,7 +734,21 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
     if (forced < 0 || dynamic) { const char* e = getenv("PDMK_ATTN_NQ"); forced = e ? atoi(e) : 0; }
 #define PDMK_DQ_ARGS (const T*)q, (const T*)k, (const T*)v, (const T*)o, (const T*)d_o, lse, delta, (T*)dq, H, Nq, Nk, q_bs, q_ld, k_bs, k_ld, \
                      v_bs, v_ld, o_bs, o_ld, dq_bs, dq_ld, scale, scale * LOG2E
-    if (forced == 2)               // 32 queries per wave: no gain in the backward (unlike the forward) - A/B only
+    // 32 rows per wave in the backward kernels too, by the forward's rule (bf16 only: the fp32 forms need > 256 registers).  With
+    // the MFMA results in ordinary VGPRs (Makefile) the wide forms are the faster ones at N = 4096 (one MI355X, B = 8, H = 5,
+    // dQ + dK/dV: 791 -> 649 us; with AGPR accumulators they were the slower ones, 853 vs 874); PDMK_ATTN_NQ_DQ / _DKV force one
+    static int f_dq = -1, f_dkv = -1;
+    if (f_dq < 0 || dynamic) {
+        const char* e = getenv("PDMK_ATTN_NQ_DQ");
+        f_dq = e ? atoi(e) : 0;
+        e = getenv("PDMK_ATTN_NQ_DKV");
+        f_dkv = e ? atoi(e) : 0;
+    }
+    constexpr bool is_bf16 = std::is_same<T, bf16>::value;
+    const int want_dq = f_dq ? f_dq : forced, want_dkv = f_dkv ? f_dkv : forced;
+    const bool wide_dq = want_dq ? want_dq == 2 : (is_bf16 && (long)((Nq + 127) / 128) * H * B >= 384 && Nk >= 256);
+    const bool wide_dkv = want_dkv ? want_dkv == 2 : (is_bf16 && (long)((Nk + 127) / 128) * H * B >= 384 && Nq >= 256);
+    if (wide_dq)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
     else
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 1>), dim3((Nq + 63) / 64, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
@@ -733,7 +769,7 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
         const long items = (long)2 * B * H * Nk * 16;
         hipLaunchKernelGGL(attn_dkv_reduce_kernel<T>, dim3((unsigned)((items + NT - 1) / NT)), dim3(NT), 0, st, ws, (T*)dk,
                            (T*)dv, B, H, Nk, nsplit, dk_bs, dk_ld, dv_bs, dv_ld);
-    } else if (forced == 2) {      // 32 keys per wave: measured slower than 16 (190 VGPRs, 65 KiB LDS) - kept for A/B only
+    } else if (wide_dkv) {         // 32 keys per wave (242 VGPRs, 65 KiB LDS)
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, false, 2>), dim3((Nk + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DKV_ARGS,
                            nullptr, 1);
     } else {
