@@ -534,20 +534,23 @@ __global__ __launch_bounds__(NT) void splitk_finish_cs_kernel(const float* __res
     const int n = blockIdx.y * 64 + cc * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
+        // (M % 64 == 0: all four sweeps are in range - no exits between them, so that their loads are in flight together)
+        float4 w[4];
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) w[sw] = *reinterpret_cast<const float4*>(ws + (m0 + sw * 16 + rr) * N + n);
+        for (int sl = 1; sl < nslab; ++sl) {
+#pragma unroll
+            for (int sw = 0; sw < 4; ++sw) {
+                const float4 u = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m0 + sw * 16 + rr) * N + n);
+                w[sw].x += u.x; w[sw].y += u.y; w[sw].z += u.z; w[sw].w += u.w;
+            }
+        }
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = make_float4(bias[n], bias[n + 1], bias[n + 2], bias[n + 3]);   // (no alignment assumed)
 #pragma unroll
         for (int sw = 0; sw < 4; ++sw) {
             const long m = m0 + sw * 16 + rr;
-            if (m >= M) break;
-            float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
-            for (int sl = 1; sl < nslab; ++sl) {
-                const float4 u = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * N + n);
-                w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
-            }
-            float v[4] = {w.x, w.y, w.z, w.w};
-            if (bias) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bias[n + e];
-            }
+            float v[4] = {w[sw].x + b4.x, w[sw].y + b4.y, w[sw].z + b4.z, w[sw].w + b4.w};
             if (rowvec) {
                 const float* rv = rowvec + (m / rows_per_b) * ldrv + n;
 #pragma unroll
