@@ -115,6 +115,7 @@ class _Ops(UNetEngine):
         self.ws = k.groupnorm_ws(self.dev, 64, 32)
         self.tape, self.train, self.macs, self.count_macs = [], False, 0, False
         self.grad_ready_cb, self.wgrad_async, self._keep, self.fuse_geglu, self.defer_fanin = None, False, [], True, False
+        self.gn_epi, self.gn_count, self.gn_miss = False, [0, 0], None     # (GroupNorm statistics from GEMM epilogues: U-Net only)
 
 
 class _LatentDist:
