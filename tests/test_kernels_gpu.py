@@ -1136,7 +1136,7 @@ def test_gemm_fused_geglu_backward_epilogue(dev, force_cfg, cand):
 @pytest.mark.parametrize("cand", [1, 2, 4, 6, 9, 10, 12, 13, 14, 15, 16, 17, 19, 21, -1])
 def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
     """pdmk_gemm_args.colstat: the per-(image, column) sums and sums of squares of the STORED bf16 output come out of the GEMM's
-    epilogue (Linear with bias + residual, a conv with the time-embedding row vector, into an accumulator slice at a column
+    epilogue as 64-bit fixed-point integers (order-independent: bit-reproducible) (Linear with bias + residual, a conv with the time-embedding row vector, into an accumulator slice at a column
     offset, accumulating over two producers), for every ring tile shape, the halo-conv shapes and the tuned plan (21 = a
     row-block id: no such epilogue there, the library launches a ring shape itself); pdmk_groupnorm_apply_colstat on these sums
     = pdmk_groupnorm_fwd on the tensor (unet_2d_blocks.py ResnetBlock2D norm1 / norm2, blocks.py:322-380)."""
@@ -1150,11 +1150,14 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         yf = y.float().reshape(Bn, rows, -1)
         return yf.sum(1), (yf * yf).sum(1)
 
+    def val(acc):                                   # 64-bit fixed point -> value
+        return acc.double() / 2.0 ** 20
+
     def check(acc, col0, y, Bn, rows, what):
         s1, s2 = sums(y, Bn, rows)
         n = y.shape[1]
-        close(acc[:, 0, col0:col0 + n], s1, 2e-4, what + " sum")
-        close(acc[:, 1, col0:col0 + n], s2, 2e-4, what + " sum of squares")
+        close(val(acc)[:, 0, col0:col0 + n], s1, 2e-4, what + " sum")
+        close(val(acc)[:, 1, col0:col0 + n], s2, 2e-4, what + " sum of squares")
 
     # Linear (proj_out: bias + residual into a strided concat view), 3 images of 256 / 64 rows
     for Bn, rows, N, K in ((3, 256, 320, 160), (2, 64, 96, 320), (5, 320, 648, 96)):
@@ -1163,7 +1166,7 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         res = rnd((M, N + 8), dev, dt)[:, 8:]
         ybuf = torch.zeros(M, N + 16, device=dev, dtype=dt)
         y = ybuf[:, 8:8 + N]
-        acc = torch.zeros(Bn, 2, N + 24, device=dev)
+        acc = torch.zeros(Bn, 2, N + 24, device=dev, dtype=torch.int64)
         k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc, 16))
         ref = (a.float() @ w.float().t() + bias + res.float())
         close(y, ref, 2e-2, "linear with statistics")
@@ -1172,7 +1175,12 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         # a second producer adds into the same accumulator columns (fp32 atomics): twice the sums
         k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc, 16))
         s1, _ = sums(y, Bn, rows)
-        close(acc[:, 0, 16:16 + N], 2 * s1, 2e-4, "two producers")
+        close(val(acc)[:, 0, 16:16 + N], 2 * s1, 2e-4, "two producers")
+        # integer atomics: the same launch adds exactly the same numbers again, in whatever order the workgroups arrive
+        acc2 = torch.zeros_like(acc)
+        for _ in range(2):
+            k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc2, 16))
+        assert torch.equal(acc2, acc), "statistics must not depend on the arrival order of the workgroups"
     # 3x3 conv with the per-image row vector (ResnetBlock2D conv1 + time embedding), whole-row and 2D halo tiles
     for Bn, Hs, Ci, Co in ((2, 16, 64, 160), (1, 32, 32, 64), (3, 8, 96, 320), (2, 64, 32, 128)):
         x = rnd((Bn, Hs, Hs, Ci), dev, dt)
@@ -1180,7 +1188,7 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         bias, rv = torch.randn(Co, device=dev), torch.randn(Bn, Co, device=dev)
         M, rows = Bn * Hs * Hs, Hs * Hs
         y = torch.zeros(M, Co, device=dev, dtype=dt)
-        acc = torch.zeros(Bn, 2, Co, device=dev)
+        acc = torch.zeros(Bn, 2, Co, device=dev, dtype=torch.int64)
         k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci),
                bias=bias, rowvec=rv, rows_per_b=rows, colstat=(acc, 0))
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rv[:, :, None, None]
@@ -1203,7 +1211,7 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         ws = torch.zeros(sk, M, N, device=dev)
         k.gemm(a, w, ws, M, N, K, K, K, N, out_f32=True, splitk=sk, accumulate=2)
         y0, y1 = torch.zeros(M, N, device=dev, dtype=dt), torch.zeros(M, N + 8, device=dev, dtype=dt)[:, :N]
-        acc = torch.zeros(Bn, 2, N + 8, device=dev)
+        acc = torch.zeros(Bn, 2, N + 8, device=dev, dtype=torch.int64)
         k.splitk_finish(ws, y0, M, N, N, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows)
         k.splitk_finish(ws, y1, M, N, N + 8, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows, colstat=(acc, 8))
         assert torch.equal(y0, y1)
@@ -1213,4 +1221,4 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
     y = torch.zeros(96, 64, device=dev, dtype=dt)
     with pytest.raises(k.PdmkError):
         k.gemm(rnd((96, 32), dev, dt), rnd((64, 32), dev, dt), y, 96, 64, 32, 32, 32, 64, rows_per_b=48,
-               colstat=(torch.zeros(2, 2, 64, device=dev), 0))
+               colstat=(torch.zeros(2, 2, 64, device=dev, dtype=torch.int64), 0))

@@ -61,6 +61,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------------------
 // Kernel-argument block of a grouped GEMM launch (pdmk_gemm_group): problem i owns the linear workgroup ids
 // [start[i], start[i] + gx[i] * gy[i]) (start[] are multiples of 8; the gap is padding workgroups that exit at once).
+// pdmk_gemm_args.colstat: one workgroup's partial sum -> the 64-bit fixed-point accumulator (integer atomic, no return value)
+__device__ __forceinline__ void cs_add(int64_t* acc, float sum) {
+    const long long q = __float2ll_rn(sum * (float)PDMK_COLSTAT_SCALE);
+    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)q);
+}
+
 struct pdmk_gemm_group_dev {
     int n;
     int start[PDMK_GEMM_GROUP_MAX + 1];

@@ -521,12 +521,13 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
 
 // The same finish with the GroupNorm statistics of the stored output (pdmk_gemm_args.colstat, for split-K producers): a block
 // owns 64 rows of one image x 64 columns; thread = (row % 16, 4-column chunk), four sweeps; the per-thread column sums of the
-// values AS STORED are added over the 16 row-threads through LDS and leave as fp32 atomics into colstat[image][0 / 1][column].
+// values AS STORED are added over the 16 row-threads through LDS and leave as fixed-point integer atomics into
+// colstat[image][0 / 1][column] (order-independent).
 template <typename T>
 __global__ __launch_bounds__(NT) void splitk_finish_cs_kernel(const float* __restrict__ ws, T* __restrict__ C, const float* __restrict__ bias,
                                                               const float* __restrict__ rowvec, const T* __restrict__ R, long M, int N,
                                                               int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int acc,
-                                                              float* __restrict__ colstat, int cs_ld) {
+                                                              int64_t* __restrict__ colstat, int cs_ld) {
     static_assert(NT == 256, "16 row-threads x 16 column chunks");
     __shared__ float part[16][2][64];
     const int tid = threadIdx.x, cc = tid & 15, rr = tid >> 4;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(NT) void splitk_finish_cs_kernel(const float* __res
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += part[r][which][col];
-            unsafeAtomicAdd(colstat + (m0 / rows_per_b) * 2 * cs_ld + (long)which * cs_ld + nn, sum);
+            cs_add(colstat + (m0 / rows_per_b) * 2 * cs_ld + (long)which * cs_ld + nn, sum);
         }
     }
 }
@@ -914,7 +915,7 @@ extern "C" int pdmk_splitk_finish(const float* ws, void* C, const float* bias, c
 }
 extern "C" int pdmk_splitk_finish_colstat(const float* ws, void* C, const float* bias, const float* rowvec, const void* R,
                                           int64_t M, int N, int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int accumulate,
-                                          float* colstat, int cs_ld, int cs_col0, int dtype, pdmk_stream s) {
+                                          int64_t* colstat, int cs_ld, int cs_col0, int dtype, pdmk_stream s) {
     if (!ws || !C || !colstat || M <= 0 || N <= 0 || (N & 3) || rows_per_b <= 0 || (rows_per_b % 64) || (M % 64) || nslab < 1 ||
         cs_col0 < 0 || cs_ld < cs_col0 + N)
         return -1;

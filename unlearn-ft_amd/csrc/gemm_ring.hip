@@ -309,7 +309,8 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
             if (CS_OK && g.colstat) {
                 // GroupNorm statistics (pdmk.h, colstat): the 64 rows of a pass belong to one image (rows_per_b % 64 == 0, whole
                 // tiles); the per-thread sums run on over the passes of that image and are flushed when the image changes or the
-                // tile ends: the RS threads of a chunk are added through the staging image, the workgroups by fp32 atomics
+                // tile ends: the RS threads of a chunk are added through the staging image (fixed order), the workgroups by 64-bit
+                // fixed-point integer atomics (order-independent: bit-reproducible)
                 const int mp0 = row_of(pass * 64);
                 const int img = mp0 / g.rows_per_b;
                 const bool flush = pass == BM / 64 - 1 || row_of((pass + 1) * 64) >= g.M || row_of((pass + 1) * 64) / g.rows_per_b != img;
@@ -329,7 +330,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
                         float sum = 0.f;
 #pragma unroll
                         for (int r = 0; r < RS; ++r) sum += stage[r * (2 * BN) + c];
-                        unsafeAtomicAdd(g.colstat + (long)img * 2 * g.cs_ld + (c < BN ? 0 : g.cs_ld) + g.cs_col0 + n0 + col, sum);
+                        cs_add(g.colstat + (long)img * 2 * g.cs_ld + (c < BN ? 0 : g.cs_ld) + g.cs_col0 + n0 + col, sum);
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) cs1[r] = cs2[r] = 0.f;

@@ -194,16 +194,16 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     __shared__ float lm[64], lr[64];
     if (nblk < 0) {
         // statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): `part` = this tensor's first column of the
-        // [B][2][cs_ld] per-(image, column) sums; group g = its gs columns, summed in double
+        // [B][2][cs_ld] per-(image, column) 64-bit fixed-point sums; group g = its gs columns
         if (tid < G) {
-            const float* c0 = part + (long)b * 2 * cs_ld + tid * gs;
-            double a0 = 0.0, a1 = 0.0;
+            const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 2 * cs_ld + tid * gs;
+            long long a0 = 0, a1 = 0;           // fixed point: exact integer sums
             for (int j = 0; j < gs; ++j) {
-                a0 += (double)c0[j];
-                a1 += (double)c0[cs_ld + j];
+                a0 += c0[j];
+                a1 += c0[cs_ld + j];
             }
-            d0[tid] = a0;
-            d1[tid] = a1;
+            d0[tid] = (double)a0 * (1.0 / PDMK_COLSTAT_SCALE);
+            d1[tid] = (double)a1 * (1.0 / PDMK_COLSTAT_SCALE);
         }
         __syncthreads();
     } else {
@@ -716,7 +716,7 @@ int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
 }  // namespace
 
 template <typename T>
-int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats, const float* colstat, int cs_ld,
+int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats, const int64_t* colstat, int cs_ld,
                      int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps, int silu, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
@@ -725,7 +725,7 @@ int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* be
     dim3 grid((HW + rpb - 1) / rpb, B);
     const int slots = (C / V + NT - 1) / NT;
 #define PDMK_GNA(S)                                                                                                   \
-    hipLaunchKernelGGL((gn_apply_kernel<T, 4, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, colstat, -1, stats, \
+    hipLaunchKernelGGL((gn_apply_kernel<T, 4, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, reinterpret_cast<const float*>(colstat), -1, stats, \
                        HW, C, ldx, ldy, G, gs, eps, silu, rpb, cs_ld)
     if (slots == 1) PDMK_GNA(1);
     else if (slots == 2) PDMK_GNA(2);
@@ -736,7 +736,7 @@ int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* be
 }
 
 extern "C" int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats,
-                                            const float* colstat, int cs_ld, int cs_col0, int B, int HW, int C, int ldx, int ldy,
+                                            const int64_t* colstat, int cs_ld, int cs_col0, int B, int HW, int C, int ldx, int ldy,
                                             int G, int gs, float eps, int silu, int dtype, pdmk_stream stream) {
     if (!x || !y || !gamma || !beta || !stats || !colstat || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || gs <= 0 || cs_col0 < 0 ||
         cs_ld < cs_col0 + G * gs)

@@ -425,7 +425,7 @@ class UNetEngine:
         if self._cs_need and (self._cs_arena is None or self._cs_arena.numel() < self._cs_need):
             # grow: the old arena is RETAINED - a captured graph of an earlier (smaller) pass still zeroes and adds into it
             self._cs_old.append(self._cs_arena)
-            self._cs_arena = torch.empty(max(self._cs_need, 1 << 16), device=self.dev, dtype=torch.float32)
+            self._cs_arena = torch.empty(max(self._cs_need, 1 << 16), device=self.dev, dtype=torch.int64)
         self._cs_off, self._cs_need = 0, 0
         self._cs_views, self._cs_cats = {}, {}
         self.gn_count = [0, 0]          # GroupNorms of this pass, of which with statistics from a producer's epilogue
@@ -442,7 +442,7 @@ class UNetEngine:
             t = self._cs_arena[self._cs_off:self._cs_off + B * 2 * cols].view(B, 2, cols)
             self._cs_off += n
             return t
-        return k.zeros((B, 2, cols), self.dev, torch.float32)
+        return k.zeros((B, 2, cols), self.dev, torch.int64)
 
     @staticmethod
     def _cs_shape_ok(M, B, ld):
