@@ -89,15 +89,18 @@ typedef struct pdmk_gemm_args {
     int32_t ldc2;        /* row stride of C2 */
     void* C2;            /* PDMK_EPI_GEGLU: optional [M, N] copy of the pre-activation (what the backward needs), or NULL */
     int64_t* colstat;    /* optional (round 3): per-(image, column) statistics of the OUTPUT for the GroupNorm that reads it next
-                            (blocks.py:318-319, 348-371: every GroupNorm's input is a GEMM output) - colstat[(b * 2 + 0) * cs_ld +
-                            cs_col0 + n] += sum over the rows of image b of C[m][n] (as stored, i.e. after bias / rowvec /
-                            residual and the rounding to bf16), [(b * 2 + 1) * ...] += the sum of squares, as 64-bit FIXED-POINT
-                            numbers (value * PDMK_COLSTAT_SCALE, round to nearest) added with integer atomics into a zeroed
-                            buffer: integer addition is associative, so the sums do not depend on the order in which the
-                            workgroups arrive - bit-reproducible, unlike float atomics (each workgroup's own partial sum is
-                            formed in a fixed order in fp32; |partial| < 2^43).  pdmk_groupnorm_apply_colstat turns them into
-                            group statistics, so the statistics pass over the tensor is not needed.  bf16, rows_per_b % 64 == 0,
-                            M % 64 == 0, N % 8 == 0, no split-K / epilogue / out_f32; LDS-DMA ring and halo kernels only */
+                            (blocks.py:318-319, 348-371: every GroupNorm's input is a GEMM output): the sum over the rows of
+                            image b of C[m][n] (as stored, i.e. after bias / rowvec / residual and the rounding to bf16) and the
+                            sum of squares, as FIXED-POINT numbers with 30 fraction bits held in two 64-bit limbs each - layout
+                            [B][4][cs_ld]: rows 0 / 1 = low / high limb of the sum (value * 2^30 = high * 2^32 + low, low in
+                            [0, 2^32)), rows 2 / 3 = the same for the sum of squares; column cs_col0 + n.  The limbs are added
+                            with integer atomics into a zeroed buffer: integer addition is associative, so the totals do not
+                            depend on the order in which the workgroups arrive - bit-reproducible, unlike float atomics (each
+                            workgroup's own partial sum is formed in a fixed order in fp32; resolution 2^-30, |partial| clamped
+                            to 2^56 - 4 * 10^9 times the largest bf16 activation an SD U-Net produces).
+                            pdmk_groupnorm_apply_colstat turns them into group statistics, so the statistics pass over the
+                            tensor is not needed.  bf16, rows_per_b % 64 == 0, M % 64 == 0, N % 8 == 0, no split-K / epilogue /
+                            out_f32; LDS-DMA ring and halo kernels only */
     int32_t cs_ld;       /* elements per accumulator row (>= cs_col0 + N: a concat buffer's accumulator has one row for all its columns) */
     int32_t cs_col0;     /* accumulator column of output column 0 */
 } pdmk_gemm_args;
@@ -142,7 +145,7 @@ int pdmk_gemm(const pdmk_gemm_args* args, pdmk_stream stream);
  * (pdmk_conv_up2_supported answers beforehand; the caller then uses conv_mode 2). */
 int pdmk_conv_up2_supported(int B, int H, int W, int Ci, int Co, int dtype);
 /* GroupNorm(+SiLU) forward whose statistics come from per-(image, column) sums a producing GEMM accumulated (pdmk_gemm_args.colstat,
- * layout [B][2][cs_ld], this tensor's columns start at cs_col0) instead of a pass over x: one launch, one read of x.  `stats`
+ * layout [B][4][cs_ld], this tensor's columns start at cs_col0) instead of a pass over x: one launch, one read of x.  `stats`
  * ([B][G][2]: mean, rstd) is written for the backward as by pdmk_groupnorm_fwd. */
 int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, const float* beta, float* stats, const int64_t* colstat,
                                  int cs_ld, int cs_col0, int B, int HW, int C, int ldx, int ldy, int G, int gs, float eps,
@@ -151,7 +154,7 @@ int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, con
  * dw3 [Co][9][Ci] += the four phase gradients dwp [4][Co][4][Ci] (fp32). */
 int pdmk_up2_pack_weights(const float* w3, void* wp, void* wpt, int Co, int Ci, int dtype, pdmk_stream stream);
 int pdmk_up2_combine_wgrad(const float* dwp, float* dw3, int Co, int Ci, pdmk_stream stream);
-#define PDMK_COLSTAT_SCALE 1048576.0 /* 2^20: fixed-point unit of the colstat accumulators */
+#define PDMK_COLSTAT_SCALE 1073741824.0 /* 2^30: fixed-point unit of the colstat accumulators (two 64-bit limbs per number) */
 #define PDMK_GEMM_GROUP_MAX 4
 int pdmk_gemm_group(const pdmk_gemm_args* args, int n, pdmk_stream stream, int32_t* grouped_out);
 /* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller
@@ -173,7 +176,7 @@ int pdmk_splitk_finish(const float* ws, void* C, const float* bias, const float*
                        int N, int ldc, int ldr, int rows_per_b, int ldrv /* 0 = N */, int nslab /* slabs in ws */,
                        int accumulate, int dtype, pdmk_stream stream);
 /* pdmk_splitk_finish that also adds the GroupNorm statistics of the stored output to `colstat` (as pdmk_gemm_args.colstat does
- * for an unsplit producer: [B][2][cs_ld] fixed-point sums / sums of squares per (image, column), integer atomics, first column cs_col0).
+ * for an unsplit producer: [B][4][cs_ld] fixed-point sums / sums of squares per (image, column), integer atomics, first column cs_col0).
  * M % 64 == 0 and rows_per_b % 64 == 0 (rows of one image per 64-row block), else -1. */
 int pdmk_splitk_finish_colstat(const float* ws, void* C, const float* bias, const float* rowvec, const void* R, int64_t M,
                                int N, int ldc, int ldr, int rows_per_b, int ldrv, int nslab, int accumulate, int64_t* colstat,

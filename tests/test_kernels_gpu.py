@@ -362,6 +362,44 @@ def test_attention(dev, dn, Nq, Nk, H):
     close(dv.view(Bn, Nk, H, D).transpose(1, 2), gv, TOL[dn] * 2, "attn dv")
 
 
+@pytest.mark.parametrize("Nq,Nk", [(128, 77), (200, 200), (256, 13)])
+def test_attention_strongly_negative_scores_with_a_key_tail(dev, Nq, Nk):
+    """Rows whose real scores are ALL far below zero (log-sum-exp < -128 in base 2) next to key blocks with missing keys: a
+    missing key has K = 0, i.e. score 0 and exp2(0 - lse) = inf - the masked tail block of the forward and of the dQ kernel must
+    keep that out of the sums (an unmasked inf * 0 poisons the whole dQ row; found by the step-parity suite after a large-lr
+    update), and the wide / narrow forms of all three kernels must agree with fp32 math."""
+    from pdm import _pdmk as k
+    torch.manual_seed(19)
+    dt = torch.bfloat16
+    Bn, H, D = 2, 2, 64
+    u = torch.ones(D, device=dev)
+    q = (4.5 * u + 0.25 * torch.randn(Bn, Nq, H, D, device=dev)).to(dt).reshape(Bn, Nq, H * D)
+    kk = (-4.5 * u + 0.25 * torch.randn(Bn, Nk, H, D, device=dev)).to(dt).reshape(Bn, Nk, H * D)
+    v = rnd((Bn, Nk, H * D), dev, dt)
+    qs, ks, os_ = (Nq * H * D, H * D), (Nk * H * D, H * D), (Nq * H * D, H * D)
+    scale = D ** -0.5
+    o = torch.zeros(Bn, Nq, H * D, device=dev, dtype=dt)
+    lse = torch.zeros(Bn, H, Nq, device=dev)
+    k.attn_fwd(q, kk, v, o, lse, Bn, H, Nq, Nk, qs, ks, ks, os_, scale)
+    assert float(lse.max()) < -128.0, float(lse.max())          # the regime under test
+    qr = q.float().reshape(Bn, Nq, H, D).transpose(1, 2).clone().requires_grad_(True)
+    kr = kk.float().reshape(Bn, Nk, H, D).transpose(1, 2).clone().requires_grad_(True)
+    vr = v.float().reshape(Bn, Nk, H, D).transpose(1, 2).clone().requires_grad_(True)
+    sc = (qr @ kr.transpose(-1, -2)) * scale
+    ref = torch.softmax(sc, -1) @ vr
+    close(o.view(Bn, Nq, H, D).transpose(1, 2), ref, 2e-2, "attn fwd, negative scores")
+    do = rnd((Bn, Nq, H * D), dev, dt)
+    gq, gk, gv = torch.autograd.grad(ref, [qr, kr, vr], do.float().view(Bn, Nq, H, D).transpose(1, 2))
+    dq, dk, dv = (torch.zeros(Bn, n, H * D, device=dev, dtype=dt) for n in (Nq, Nk, Nk))
+    delta = torch.zeros(Bn, H, Nq, device=dev)
+    k.attn_bwd(q, kk, v, o, do, lse, delta, dq, dk, dv, Bn, H, Nq, Nk, qs, ks, ks, os_, os_, ks, ks, scale)
+    for name, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+        assert torch.isfinite(got.float()).all(), name
+    close(dq.view(Bn, Nq, H, D).transpose(1, 2), gq, 8e-2, "attn dq, negative scores")   # (ill-conditioned on purpose)
+    close(dk.view(Bn, Nk, H, D).transpose(1, 2), gk, 8e-2, "attn dk, negative scores")
+    close(dv.view(Bn, Nk, H, D).transpose(1, 2), gv, 4e-2, "attn dv, negative scores")
+
+
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
 def test_elementwise_family(dev, dn):
     from pdm import _pdmk as k
@@ -1150,8 +1188,9 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         yf = y.float().reshape(Bn, rows, -1)
         return yf.sum(1), (yf * yf).sum(1)
 
-    def val(acc):                                   # 64-bit fixed point -> value
-        return acc.double() / 2.0 ** 20
+    def val(acc):                                   # fixed point, 30 fraction bits in two limbs (low, high) -> [B, 2, cols] values
+        a = acc.double()
+        return (a[:, 1::2] * 2.0 ** 32 + a[:, 0::2]) / 2.0 ** 30
 
     def check(acc, col0, y, Bn, rows, what):
         s1, s2 = sums(y, Bn, rows)
@@ -1166,7 +1205,7 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         res = rnd((M, N + 8), dev, dt)[:, 8:]
         ybuf = torch.zeros(M, N + 16, device=dev, dtype=dt)
         y = ybuf[:, 8:8 + N]
-        acc = torch.zeros(Bn, 2, N + 24, device=dev, dtype=torch.int64)
+        acc = torch.zeros(Bn, 4, N + 24, device=dev, dtype=torch.int64)
         k.gemm(a, w, y, M, N, K, K, K, N + 16, bias=bias, R=res, ldr=N + 8, rows_per_b=rows, colstat=(acc, 16))
         ref = (a.float() @ w.float().t() + bias + res.float())
         close(y, ref, 2e-2, "linear with statistics")
@@ -1188,7 +1227,7 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         bias, rv = torch.randn(Co, device=dev), torch.randn(Bn, Co, device=dev)
         M, rows = Bn * Hs * Hs, Hs * Hs
         y = torch.zeros(M, Co, device=dev, dtype=dt)
-        acc = torch.zeros(Bn, 2, Co, device=dev, dtype=torch.int64)
+        acc = torch.zeros(Bn, 4, Co, device=dev, dtype=torch.int64)
         k.gemm(x, conv_w_pack(w), y, M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(Bn, Hs, Hs, Ci, Hs, Hs, 0, Ci),
                bias=bias, rowvec=rv, rows_per_b=rows, colstat=(acc, 0))
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rv[:, :, None, None]
@@ -1211,14 +1250,22 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
         ws = torch.zeros(sk, M, N, device=dev)
         k.gemm(a, w, ws, M, N, K, K, K, N, out_f32=True, splitk=sk, accumulate=2)
         y0, y1 = torch.zeros(M, N, device=dev, dtype=dt), torch.zeros(M, N + 8, device=dev, dtype=dt)[:, :N]
-        acc = torch.zeros(Bn, 2, N + 8, device=dev, dtype=torch.int64)
+        acc = torch.zeros(Bn, 4, N + 8, device=dev, dtype=torch.int64)
         k.splitk_finish(ws, y0, M, N, N, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows)
         k.splitk_finish(ws, y1, M, N, N + 8, sk, bias=bias, rowvec=rv, R=res, ldr=N, rows_per_b=rows, colstat=(acc, 8))
         assert torch.equal(y0, y1)
         check(acc, 8, y1, Bn, rows, f"split-K finish B{Bn} rows{rows} N{N}")
         assert (acc[:, :, :8] == 0).all()
+    # activations far outside any sane range (a diverged run: 3e6, sums of squares of 1e15 per image) still give exact statistics
+    Bn, rows, N, K = 2, 256, 64, 64
+    a = (3.0e6 * torch.sign(torch.randn(Bn * rows, K, device=dev))).to(dt)
+    w = torch.eye(N, K, device=dev).to(dt)
+    y = torch.zeros(Bn * rows, N, device=dev, dtype=dt)
+    acc = torch.zeros(Bn, 4, N, device=dev, dtype=torch.int64)
+    k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc, 0))
+    check(acc, 0, y, Bn, rows, "huge activations")
     # shapes the epilogue does not take are refused (-1), never silently skipped
     y = torch.zeros(96, 64, device=dev, dtype=dt)
     with pytest.raises(k.PdmkError):
         k.gemm(rnd((96, 32), dev, dt), rnd((64, 32), dev, dt), y, 96, 64, 32, 32, 32, 64, rows_per_b=48,
-               colstat=(torch.zeros(2, 2, 64, device=dev, dtype=torch.int64), 0))
+               colstat=(torch.zeros(2, 4, 64, device=dev, dtype=torch.int64), 0))

@@ -439,7 +439,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(const T* __restrict__ 
                     dp[j] = MM::mma(oa, vf[j][kk], dp[j]);
                 }
             }
-            // (keys past the end need no mask: their dK / dV columns are never stored; queries past the end have -lse = -inf)
+            // (keys past the end need no mask here: a key is an output COLUMN of both products, so whatever its probabilities are -
+            // even inf when exp2(-lse) overflows - stays in dK / dV columns that are never stored; queries past the end have
+            // -lse = -inf, i.e. p = 0)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
 #pragma unroll
@@ -593,15 +595,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
         for (int i = 0; i < 4; ++i) dqt[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // One key block.  TAIL (the last block when Nk is not a multiple of KVB) zeroes the probabilities of keys past the end and is a
+    // second copy of the body: the full blocks carry no mask arithmetic (the select per score element was half of this loop's VALU
+    // instructions).  The mask itself cannot go: a missing key has K = 0, so s = 0 and p = exp2(-lse), which overflows when the
+    // row's real scores are all below -128 (base 2) - inf * 0 in the dQ = dS K product would poison the whole row.
     int cur = 0;
-    for (int kb = 0; kb < Nk; kb += KVB) {
+    auto block = [&](auto tail_c, const int kb) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         const bool more = kb + KVB < Nk;
         if (more) {
             KIO::load(rk_, rk, k_ld, kb + KVB, Nk, tid);
             KIO::load(rv_, rv, v_ld, kb + KVB, Nk, tid);
         }
-        // (no mask for keys past the end: their K rows are hardware zero fill, so whatever finite dS they get adds nothing to
-        // dQ = dS K - the select per score element was half of this VALU-bound loop's instructions)
         f32x4 dst[NQ][NKT];                 // dS^T[key = 16t + 4g + r][query]
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -626,7 +631,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {          // two score elements per v_pk_fma_f32 / v_pk_mul_f32
                     const f32x2 e2 = __builtin_elementwise_fma(f32x2{s[n][r], s[n][r + 1]}, f32x2{scale2, scale2}, f32x2{nl2[n], nl2[n]});
-                    const f32x2 d2 = f32x2{__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])} * f32x2{dp[n][r], dp[n][r + 1]};
+                    f32x2 pv = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                    if (TAIL) {
+                        if (kb + t * 16 + (lane >> 4) * 4 + r >= Nk) pv[0] = 0.f;
+                        if (kb + t * 16 + (lane >> 4) * 4 + r + 1 >= Nk) pv[1] = 0.f;
+                    }
+                    const f32x2 d2 = pv * f32x2{dp[n][r], dp[n][r + 1]};
                     dst[n][t][r] = d2[0];
                     dst[n][t][r + 1] = d2[1];
                 }
@@ -652,7 +662,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(const T* __restrict__ q
         }
         __syncthreads();
         cur ^= 1;
-    }
+    };
+    const int nfull = Nk / KVB * KVB;
+    for (int kb = 0; kb < nfull; kb += KVB) block(std::false_type{}, kb);
+    if (nfull < Nk) block(std::true_type{}, nfull);
 #pragma unroll
     for (int n = 0; n < NQ; ++n) stage_t<T>(Qs + (wave * NQ + n) * 16 * RS, dqt[n], scale, lane);
     __syncthreads();

@@ -61,10 +61,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------------------
 // Kernel-argument block of a grouped GEMM launch (pdmk_gemm_group): problem i owns the linear workgroup ids
 // [start[i], start[i] + gx[i] * gy[i]) (start[] are multiples of 8; the gap is padding workgroups that exit at once).
-// pdmk_gemm_args.colstat: one workgroup's partial sum -> the 64-bit fixed-point accumulator (integer atomic, no return value)
-__device__ __forceinline__ void cs_add(int64_t* acc, float sum) {
-    const long long q = __float2ll_rn(sum * (float)PDMK_COLSTAT_SCALE);
-    atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)q);
+// pdmk_gemm_args.colstat: one workgroup's partial sum -> the fixed-point accumulator (30 fraction bits, two 64-bit limbs at
+// `lo` and `lo + cs_ld`; integer atomics, no return value).  value * 2^30 = hi * 2^32 + low with low in [0, 2^32): both limbs
+// have > 2^20 additions of headroom, and their totals do not depend on the order of the additions.
+__device__ __forceinline__ void cs_add(int64_t* lo, int cs_ld, float sum) {
+    sum = fminf(fmaxf(sum, -7.2e16f), 7.2e16f);                       // 2^56: keeps the high limb inside 64 bits
+    const double d = (double)sum * PDMK_COLSTAT_SCALE;                // exact (power of two)
+    const double hd = floor(d * (1.0 / 4294967296.0));
+    const long long hi = (long long)hd;
+    const unsigned long long low = (unsigned long long)(d - hd * 4294967296.0);   // exact, [0, 2^32)
+    atomicAdd(reinterpret_cast<unsigned long long*>(lo), low);
+    atomicAdd(reinterpret_cast<unsigned long long*>(lo + cs_ld), (unsigned long long)hi);
+}
+// the value of one accumulator column (limbs already summed over a group's columns or not)
+__device__ __forceinline__ double cs_value(long long low, long long hi) {
+    return ((double)hi * 4294967296.0 + (double)low) * (1.0 / PDMK_COLSTAT_SCALE);
 }
 
 struct pdmk_gemm_group_dev {

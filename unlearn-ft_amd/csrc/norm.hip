@@ -194,16 +194,18 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     __shared__ float lm[64], lr[64];
     if (nblk < 0) {
         // statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): `part` = this tensor's first column of the
-        // [B][2][cs_ld] per-(image, column) 64-bit fixed-point sums; group g = its gs columns
+        // [B][4][cs_ld] per-(image, column) fixed-point sums (two limbs each); group g = its gs columns
         if (tid < G) {
-            const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 2 * cs_ld + tid * gs;
-            long long a0 = 0, a1 = 0;           // fixed point: exact integer sums
+            const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld + tid * gs;
+            long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;          // fixed point, two limbs: exact integer sums over the group's columns
             for (int j = 0; j < gs; ++j) {
-                a0 += c0[j];
-                a1 += c0[cs_ld + j];
+                l0 += c0[j];
+                h0 += c0[cs_ld + j];
+                l1 += c0[2 * cs_ld + j];
+                h1 += c0[3 * cs_ld + j];
             }
-            d0[tid] = (double)a0 * (1.0 / PDMK_COLSTAT_SCALE);
-            d1[tid] = (double)a1 * (1.0 / PDMK_COLSTAT_SCALE);
+            d0[tid] = cs_value(l0, h0);
+            d1[tid] = cs_value(l1, h1);
         }
         __syncthreads();
     } else {

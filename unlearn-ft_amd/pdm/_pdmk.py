@@ -288,7 +288,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     g.dtype = dt(A) if dtype is None else dtype
     g.out_f32, g.accumulate, g.splitk, g.alpha = int(out_f32), int(accumulate), int(splitk), float(alpha)
     g.epilogue, g.C2, g.ldc2 = int(epilogue), _p(C2), int(ldc2)
-    if colstat is not None:          # (accumulator [B, 2, cs_ld] fp32, first accumulator column of this output)
+    if colstat is not None:          # (accumulator [B, 4, cs_ld] int64 limbs, first accumulator column of this output)
         g.colstat, g.cs_ld, g.cs_col0 = _p(colstat[0]), colstat[0].shape[2], int(colstat[1])
     shape = (M, N, K, int(splitk))
     if RECORD is not None:
@@ -472,7 +472,7 @@ def gemm_auto(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, row
 @_recordable("splitk_finish")
 def splitk_finish(ws, Cout, M, N, ldc, nslab, *, bias=None, rowvec=None, R=None, ldr=0, rows_per_b=0, ldrv=0,
                   accumulate=False, colstat=None):
-    """colstat = (accumulator [B, 2, ld], first column): the GroupNorm statistics of the stored output leave with this pass."""
+    """colstat = (accumulator [B, 4, ld] int64, first column): the GroupNorm statistics of the stored output leave with this pass."""
     if colstat is not None:
         _chk(_lib.pdmk_splitk_finish_colstat(_p(ws), _p(Cout), _p(bias), _p(rowvec), _p(R), M, N, ldc, ldr, rows_per_b, ldrv,
                                              nslab, int(accumulate), _p(colstat[0]), colstat[0].shape[2], int(colstat[1]),
@@ -537,7 +537,7 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
 
 @_recordable("groupnorm_apply_colstat")
 def groupnorm_apply_colstat(x, y, gamma, beta, stats, colstat, col0, B, HW, Cc, ldx, ldy, G, gs, eps, silu):
-    """GroupNorm(+SiLU) forward with the statistics taken from a producing GEMM's epilogue sums (colstat [B, 2, cs_ld])."""
+    """GroupNorm(+SiLU) forward with the statistics taken from a producing GEMM's epilogue sums (colstat [B, 4, cs_ld] int64 limbs)."""
     _chk(_lib.pdmk_groupnorm_apply_colstat(_p(x), _p(y), _p(gamma), _p(beta), _p(stats), _p(colstat), colstat.shape[2], int(col0),
                                            B, HW, Cc, ldx, ldy, G, gs, eps, int(silu), dt(x), _st()),
          "pdmk_groupnorm_apply_colstat")

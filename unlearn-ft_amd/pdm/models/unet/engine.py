@@ -433,23 +433,22 @@ class UNetEngine:
             k.zero_(self._cs_arena)
 
     def _cs_alloc(self, B, cols):
-        """Zeroed accumulator [B, 2, cols] (a slice of the pass's arena; the first pass of a new shape sizes the arena and
+        """Zeroed accumulator [B, 4, cols] (int64 limbs, pdmk.h colstat; a slice of the pass's arena; the first pass of a new shape sizes the arena and
         zeroes its accumulators one by one)."""
-        n = B * 2 * cols
-        n = (n + 3) & ~3
+        n = B * 4 * cols
         self._cs_need += n
         if self._cs_arena is not None and self._cs_off + n <= self._cs_arena.numel():
-            t = self._cs_arena[self._cs_off:self._cs_off + B * 2 * cols].view(B, 2, cols)
+            t = self._cs_arena[self._cs_off:self._cs_off + n].view(B, 4, cols)
             self._cs_off += n
             return t
-        return k.zeros((B, 2, cols), self.dev, torch.int64)
+        return k.zeros((B, 4, cols), self.dev, torch.int64)
 
     @staticmethod
     def _cs_shape_ok(M, B, ld):
         return B > 0 and M % B == 0 and (M // B) % 64 == 0 and ld % 8 == 0
 
     def _cs_for(self, y, B, rows_per_b, M, N, view=False):
-        """(accumulator [B, 2, ld], first column) for a GEMM that writes `y` [M, N] and whose output a GroupNorm reads next -
+        """(accumulator [B, 4, ld], first column) for a GEMM that writes `y` [M, N] and whose output a GroupNorm reads next -
         or None when the statistics epilogue cannot take the shape (the GroupNorm then runs its own statistics pass).
         view: y is a concat-buffer view handed out by _skip_view / _left_view - the sums go to that buffer's accumulator, at the
         view's columns, so that the GroupNorm over the whole concat finds both halves in one place."""
