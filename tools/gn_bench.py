@@ -27,4 +27,7 @@ for B, HW, C in [(8, 4096, 320), (8, 4096, 640), (8, 4096, 960), (8, 1024, 640),
     tf = gtime(lambda: k.groupnorm_fwd(x, y, gamma, beta, stats, ws, B, HW, C, C, C, G, gs, 1e-5, True))
     tb = gtime(lambda: k.groupnorm_bwd(x, dy, dx, gamma, beta, stats, dg, db, ws, B, HW, C, C, C, C, G, gs, True, False))
     nb = B * HW * C * 2
-    print(f"B{B} HW{HW} C{C}: fwd {tf:6.1f} us ({3 * nb / tf / 1e6:5.2f} TB/s of 2R+1W)   bwd {tb:6.1f} us ({5 * nb / tb / 1e6:5.2f} TB/s of 4R+1W)")
+    acc = torch.zeros(B, 4, C, device=dev, dtype=torch.int64)       # (the values do not matter for the timing)
+    ta = gtime(lambda: k.groupnorm_apply_colstat(x, y, gamma, beta, stats, acc, 0, B, HW, C, C, C, G, gs, 1e-5, True))
+    tc = gtime(lambda: y.copy_(x))
+    print(f"B{B} HW{HW} C{C}: fwd {tf:6.1f} us ({3 * nb / tf / 1e6:5.2f} TB/s of 2R+1W)   bwd {tb:6.1f} us ({5 * nb / tb / 1e6:5.2f} TB/s of 4R+1W)   apply-only {ta:6.1f} us ({2 * nb / ta / 1e6:5.2f} TB/s of 1R+1W; torch copy {tc:6.1f} us)")

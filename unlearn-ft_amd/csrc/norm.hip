@@ -185,38 +185,95 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
                                                       int C, int ldx, int ldy, int G, int gs, float eps, int silu,
                                                       int rows_per_blk, int cs_ld = 0) {
     constexpr int V = Vec<T>::N;
+    typedef typename Vec<T>::raw Raw;
     const int nchunks = C / V;
     const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
+    const int cr = G * gs;
     __shared__ double scr[2][NT], d0[64], d1[64];
     __shared__ float lm[64], lr[64];
+    // Everything that does not depend on the statistics is issued FIRST - this thread's gamma / beta chunks and its first sweep of
+    // rows - so that those loads are in flight while the block works out mean / rstd (a chain of an L2 read, an LDS reduction and
+    // a double-precision sqrt: 3-4 us per block, which every block of the grid pays at the same time; with the loads behind it the
+    // kernel streamed at 2.5 TB/s where a plain copy of the same tensor reaches 6.4, tools/gn_bench.py).
+    const bool active = ro < mp.rif;
+    const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    float gmv[SLOTS][V], btv[SLOTS][V];
+    Raw pre[SLOTS][UNR];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+        if (active && c < nchunks && c * V + V <= cr && vec_gb) {       // whole chunk inside the normalised channels: 16-byte loads
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * V + e), b4 = *reinterpret_cast<const float4*>(beta + c * V + e);
+                gmv[sl][e] = g4.x; gmv[sl][e + 1] = g4.y; gmv[sl][e + 2] = g4.z; gmv[sl][e + 3] = g4.w;
+                btv[sl][e] = b4.x; btv[sl][e + 1] = b4.y; btv[sl][e + 2] = b4.z; btv[sl][e + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c * V + e;
+                const bool ok = active && c < nchunks && ch < cr;
+                gmv[sl][e] = ok ? gamma[ch] : 0.f;
+                btv[sl][e] = ok ? beta[ch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rr = r0 + ro + u * mp.rif;
+            if (active && c < nchunks && rr < r1) pre[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rr) * ldx + c * V);
+        }
+    }
     if (nblk < 0) {
         // statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): `part` = this tensor's first column of the
-        // [B][4][cs_ld] per-(image, column) fixed-point sums (two limbs each); group g = its gs columns
-        if (tid < G) {
-            const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld + tid * gs;
-            long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;          // fixed point, two limbs: exact integer sums over the group's columns
-            for (int j = 0; j < gs; ++j) {
-                l0 += c0[j];
-                h0 += c0[cs_ld + j];
-                l1 += c0[2 * cs_ld + j];
-                h1 += c0[3 * cs_ld + j];
+        // [B][4][cs_ld] per-(image, column) fixed-point sums (two limbs each); group g = its gs columns.
+        // 256 / 64 = 4 threads per group (G <= 64): thread (g, p) adds the limbs of columns p, p + 4, ... of its group in
+        // registers (independent loads, all in flight), the four partners are folded with two shuffles.  Exact integer sums, no
+        // atomics: LDS atomics here put 40 same-address adds of one group into one wave instruction - 8 us per block.
+        const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld;
+        const int g = tid >> 2, pth = tid & 3;
+        long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+        if (g < G) {
+            const long long* cg = c0 + g * gs;
+#pragma unroll 4
+            for (int j = pth; j < gs; j += 4) {
+                l0 += cg[j];
+                h0 += cg[cs_ld + j];
+                l1 += cg[2 * cs_ld + j];
+                h1 += cg[3 * cs_ld + j];
             }
-            d0[tid] = cs_value(l0, h0);
-            d1[tid] = cs_value(l1, h1);
+        }
+#pragma unroll
+        for (int m = 1; m < 4; m <<= 1) {
+            l0 += __shfl_xor(l0, m, 64);
+            h0 += __shfl_xor(h0, m, 64);
+            l1 += __shfl_xor(l1, m, 64);
+            h1 += __shfl_xor(h1, m, 64);
+        }
+        if (g < G && pth == 0) {
+            d0[g] = cs_value(l0, h0);
+            d1[g] = cs_value(l1, h1);
         }
         __syncthreads();
     } else {
         gn_sum_slabs(part, b, nblk, G, d0, d1, scr);
     }
     if (tid < G) {
-        const double n = (double)HW * gs;
-        const double mean = d0[tid] / n;
-        double var = d1[tid] / n - mean * mean;
+        // (double only where the cancellation is: E[x^2] - mean^2.  The division and the square root are fp32 - 1 / n by one v_rcp
+        // refined once, rsqrt by v_rsq refined once: the fp64 div + sqrt they replace were ~1 us of every block's prologue)
+        const float nf = (float)HW * (float)gs;
+        float rn = __frcp_rn(nf);
+        rn = rn * (2.0f - nf * rn);
+        const double inv_n = (double)rn;
+        const double mean = d0[tid] * inv_n;
+        double var = d1[tid] * inv_n - mean * mean;
         if (var < 0) var = 0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float ve = (float)(var + (double)eps);
+        float rstd = __frsqrt_rn(ve);
+        rstd = rstd * (1.5f - 0.5f * ve * rstd * rstd);
         lm[tid] = (float)mean;
         lr[tid] = rstd;
         if (blockIdx.x == 0) {
@@ -225,45 +282,53 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
         }
     }
     __syncthreads();
-    if (ro >= mp.rif) return;
-    const int cr = G * gs;
+    if (!active) return;
     float sc[SLOTS][V], sh[SLOTS][V];   // y = x*sc + sh  (pad channels: 0)
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
+        int g = (c * V) / gs, rem = c * V - g * gs;          // one division per chunk; the group index then steps with the channel
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int ch = c * V + e;
             sc[sl][e] = sh[sl][e] = 0.f;
             if (c < nchunks && ch < cr) {
-                const int g = ch / gs;
-                const float a = lr[g] * gamma[ch];
+                const float a = lr[g] * gmv[sl][e];
                 sc[sl][e] = a;
-                sh[sl][e] = beta[ch] - lm[g] * a;
+                sh[sl][e] = btv[sl][e] - lm[g] * a;
             }
+            if (++rem == gs) { rem = 0; ++g; }
         }
     }
-    for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
+    const int step = mp.rif * UNR;
+    for (int r = r0 + ro; r < r1; r += step) {
+        Raw cur[SLOTS][UNR];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                cur[sl][u] = pre[sl][u];
+                const int rn = r + step + u * mp.rif;             // the next sweep's loads go out before this sweep's arithmetic
+                if (c < nchunks && rn < r1) pre[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rn) * ldx + c * V);
+            }
+        }
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[UNR][V];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int rr = r + u * mp.rif;
-                    if (rr < r1) Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
-                }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int rr = r + u * mp.rif;
                     if (rr < r1) {
+                        float f[V];
+                        Vec<T>::unpack(cur[sl][u], f);
 #pragma unroll
                         for (int e = 0; e < V; ++e) {
-                            const float z = f[u][e] * sc[sl][e] + sh[sl][e];
-                            f[u][e] = silu ? silu_f(z) : z;
+                            const float z = f[e] * sc[sl][e] + sh[sl][e];
+                            f[e] = silu ? silu_f(z) : z;
                         }
-                        Vec<T>::store(y + ((long)b * HW + rr) * ldy + c * V, f[u]);
+                        Vec<T>::store(y + ((long)b * HW + rr) * ldy + c * V, f);
                     }
                 }
             }
@@ -392,6 +457,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                                                           int accumulate, int rows_per_blk, const T* __restrict__ add,
                                                           int ldadd) {
     constexpr int V = Vec<T>::N;
+    typedef typename Vec<T>::raw Raw;
     const int nchunks = C / V;
     const GnMap2 mp = gn_map2(nchunks);
     const int tid = threadIdx.x, cb = tid % mp.tpr, ro = tid / mp.tpr;
@@ -399,58 +465,106 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
     const int cr = G * gs;
     __shared__ double scr[2][NT], d0[64], d1[64];
-    gn_sum_slabs(gpart, b, nblk, G, d0, d1, scr);
-    if (ro >= mp.rif) return;
-    const double invn = 1.0 / ((double)HW * gs);
-    float mean[SLOTS][V], rstd[SLOTS][V], gm[SLOTS][V], bt[SLOTS][V], c1[SLOTS][V], c2[SLOTS][V];
+    __shared__ float sm[64], sr[64];
+    // as gn_apply_kernel: what does not depend on the group sums goes out first (gamma / beta chunks, the (mean, rstd) pairs, the
+    // first sweep of x / dy rows), so that it is in flight while the block adds up the slabs
+    const bool active = ro < mp.rif;
+    const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    float gm[SLOTS][V], bt[SLOTS][V];
+    Raw px[SLOTS][UNR], pd[SLOTS][UNR];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
+        if (active && c < nchunks && c * V + V <= cr && vec_gb) {
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const int ch = c * V + e;
-            mean[sl][e] = rstd[sl][e] = gm[sl][e] = bt[sl][e] = c1[sl][e] = c2[sl][e] = 0.f;
-            if (c < nchunks && ch < cr) {
-                const int g = ch / gs;
-                mean[sl][e] = stats[((long)b * G + g) * 2];
-                rstd[sl][e] = stats[((long)b * G + g) * 2 + 1];
-                gm[sl][e] = gamma[ch];
-                bt[sl][e] = beta[ch];
-                c1[sl][e] = (float)(d0[g] * invn);
-                c2[sl][e] = (float)(d1[g] * invn);
+            for (int e = 0; e < V; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * V + e), b4 = *reinterpret_cast<const float4*>(beta + c * V + e);
+                gm[sl][e] = g4.x; gm[sl][e + 1] = g4.y; gm[sl][e + 2] = g4.z; gm[sl][e + 3] = g4.w;
+                bt[sl][e] = b4.x; bt[sl][e + 1] = b4.y; bt[sl][e + 2] = b4.z; bt[sl][e + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c * V + e;
+                const bool ok = active && c < nchunks && ch < cr;
+                gm[sl][e] = ok ? gamma[ch] : 0.f;
+                bt[sl][e] = ok ? beta[ch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rr = r0 + ro + u * mp.rif;
+            if (active && c < nchunks && rr < r1) {
+                px[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rr) * ldx + c * V);
+                pd[sl][u] = Vec<T>::load_raw(dy + ((long)b * HW + rr) * lddy + c * V);
             }
         }
     }
-    for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
+    if (tid < G) {
+        sm[tid] = stats[((long)b * G + tid) * 2];
+        sr[tid] = stats[((long)b * G + tid) * 2 + 1];
+    }
+    gn_sum_slabs(gpart, b, nblk, G, d0, d1, scr);          // (ends with a barrier: sm / sr are visible too)
+    if (!active) return;
+    const float invn = 1.0f / ((float)HW * (float)gs);
+    float mean[SLOTS][V], rstd[SLOTS][V], c1[SLOTS][V], c2[SLOTS][V];
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+        int g = (c * V) / gs, rem = c * V - g * gs;          // one division per chunk; the group index then steps with the channel
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const int ch = c * V + e;
+            mean[sl][e] = rstd[sl][e] = c1[sl][e] = c2[sl][e] = 0.f;
+            if (c < nchunks && ch < cr) {
+                mean[sl][e] = sm[g];
+                rstd[sl][e] = sr[g];
+                c1[sl][e] = (float)d0[g] * invn;
+                c2[sl][e] = (float)d1[g] * invn;
+            }
+            if (++rem == gs) { rem = 0; ++g; }
+        }
+    }
+    const int step = mp.rif * UNR;
+    for (int r = r0 + ro; r < r1; r += step) {
+        Raw cx[SLOTS][UNR], cd[SLOTS][UNR];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = cb + mp.tpr * sl;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                cx[sl][u] = px[sl][u];
+                cd[sl][u] = pd[sl][u];
+                const int rn = r + step + u * mp.rif;             // the next sweep's loads go out before this sweep's arithmetic
+                if (c < nchunks && rn < r1) {
+                    px[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rn) * ldx + c * V);
+                    pd[sl][u] = Vec<T>::load_raw(dy + ((long)b * HW + rn) * lddy + c * V);
+                }
+            }
+        }
 #pragma unroll
         for (int sl = 0; sl < SLOTS; ++sl) {
             const int c = cb + mp.tpr * sl;
             if (c < nchunks) {
-                float f[UNR][V], d[UNR][V], o[UNR][V], a2[UNR][V];
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int rr = r + u * mp.rif;
                     if (rr < r1) {
-                        Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
-                        Vec<T>::load(dy + ((long)b * HW + rr) * lddy + c * V, d[u]);
-                        if (accumulate) Vec<T>::load(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
-                        if (add) Vec<T>::load(add + ((long)b * HW + rr) * ldadd + c * V, a2[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int rr = r + u * mp.rif;
-                    if (rr < r1) {
+                        float f[V], d[V], o[V], a2[V];
+                        Vec<T>::unpack(cx[sl][u], f);
+                        Vec<T>::unpack(cd[sl][u], d);
+                        if (accumulate) Vec<T>::load(dx + ((long)b * HW + rr) * lddx + c * V, o);
+                        if (add) Vec<T>::load(add + ((long)b * HW + rr) * ldadd + c * V, a2);
 #pragma unroll
                         for (int e = 0; e < V; ++e) {
-                            const float xh = (f[u][e] - mean[sl][e]) * rstd[sl][e];
-                            float dz = d[u][e];
+                            const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
+                            float dz = d[e];
                             if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
                             float v = rstd[sl][e] * (gm[sl][e] * dz - c1[sl][e] - xh * c2[sl][e]);
-                            if (add) v += a2[u][e];           // a second finished gradient of x (residual fan-in) folded in
-                            o[u][e] = accumulate ? o[u][e] + v : v;
+                            if (add) v += a2[e];           // a second finished gradient of x (residual fan-in) folded in
+                            o[e] = accumulate ? o[e] + v : v;
                         }
-                        Vec<T>::store(dx + ((long)b * HW + rr) * lddx + c * V, o[u]);
+                        Vec<T>::store(dx + ((long)b * HW + rr) * lddx + c * V, o);
                     }
                 }
             }
@@ -723,8 +837,8 @@ int gn_apply_colstat(const void* x, void* y, const float* gamma, const float* be
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || ldy % V || G > 64 || G * gs > C || C / V > MAXS * NT) return -1;
     const GnMap2 mp = gn_map2(C / V);
-    const int rpb = gn_rows_per_blk(B, HW, mp.rif * 4, 1024, 1 << 20);
-    dim3 grid((HW + rpb - 1) / rpb, B);
+    const int rpb = gn_rows_per_blk(B, HW, mp.rif * 4, 1024, 1 << 20);     // (256 ... 1024 blocks and 2 / 4 / 8 rows in flight per thread
+    dim3 grid((HW + rpb - 1) / rpb, B);                                    //  measure the same, tools/gn_dbg.py)
     const int slots = (C / V + NT - 1) / NT;
 #define PDMK_GNA(S)                                                                                                   \
     hipLaunchKernelGGL((gn_apply_kernel<T, 4, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, reinterpret_cast<const float*>(colstat), -1, stats, \
