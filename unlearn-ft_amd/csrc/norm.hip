@@ -354,53 +354,103 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ 
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(HW, r0 + rows_per_blk);
     const int cr = G * gs;
-    float mean[SLOTS][V], rstd[SLOTS][V], gm[SLOTS][V], bt[SLOTS][V];
-    float a1[SLOTS][V], a2[SLOTS][V];
+    typedef typename Vec<T>::raw Raw;
+    float a1[SLOTS][V], a2[SLOTS][V], mean[SLOTS][V], rstd[SLOTS][V], gm[SLOTS][V], bt[SLOTS][V];
+    // as gn_apply_kernel: 16-byte gamma / beta loads and the first sweep of rows go out first, (mean, rstd) through LDS (one
+    // coalesced load per group instead of two scalar loads and a division per channel), then a register ping-pong over the sweeps
+    __shared__ float sm[64], sr[64];
+    const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    Raw px[SLOTS][UNR], pd[SLOTS][UNR];
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = cb + mp.tpr * sl;
+        if (active && c < nchunks && c * V + V <= cr && vec_gb) {
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * V + e), b4 = *reinterpret_cast<const float4*>(beta + c * V + e);
+                gm[sl][e] = g4.x; gm[sl][e + 1] = g4.y; gm[sl][e + 2] = g4.z; gm[sl][e + 3] = g4.w;
+                bt[sl][e] = b4.x; bt[sl][e + 1] = b4.y; bt[sl][e + 2] = b4.z; bt[sl][e + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const int ch = c * V + e;
+                const bool ok = active && c < nchunks && ch < cr;
+                gm[sl][e] = ok ? gamma[ch] : 0.f;
+                bt[sl][e] = ok ? beta[ch] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int rr = r0 + ro + u * mp.rif;
+            if (active && c < nchunks && rr < r1) {
+                px[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rr) * ldx + c * V);
+                pd[sl][u] = Vec<T>::load_raw(dy + ((long)b * HW + rr) * lddy + c * V);
+            }
+        }
+    }
+    if (tid < G) {
+        sm[tid] = stats[((long)b * G + tid) * 2];
+        sr[tid] = stats[((long)b * G + tid) * 2 + 1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int c = cb + mp.tpr * sl;
+        int g = (c * V) / gs, rem = c * V - g * gs;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const int ch = c * V + e;
             a1[sl][e] = a2[sl][e] = 0.f;
-            mean[sl][e] = rstd[sl][e] = gm[sl][e] = bt[sl][e] = 0.f;
+            mean[sl][e] = rstd[sl][e] = 0.f;
             if (c < nchunks && ch < cr) {
-                const int g = ch / gs;
-                mean[sl][e] = stats[((long)b * G + g) * 2];
-                rstd[sl][e] = stats[((long)b * G + g) * 2 + 1];
-                gm[sl][e] = gamma[ch];
-                bt[sl][e] = beta[ch];
+                mean[sl][e] = sm[g];
+                rstd[sl][e] = sr[g];
+            } else {
+                gm[sl][e] = bt[sl][e] = 0.f;
             }
+            if (++rem == gs) { rem = 0; ++g; }
         }
     }
     if (active) {
-        for (int r = r0 + ro; r < r1; r += mp.rif * UNR) {
+        const int step = mp.rif * UNR;
+        for (int r = r0 + ro; r < r1; r += step) {
+            Raw cx[SLOTS][UNR], cd[SLOTS][UNR];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = cb + mp.tpr * sl;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    cx[sl][u] = px[sl][u];
+                    cd[sl][u] = pd[sl][u];
+                    const int rn = r + step + u * mp.rif;
+                    if (c < nchunks && rn < r1) {
+                        px[sl][u] = Vec<T>::load_raw(x + ((long)b * HW + rn) * ldx + c * V);
+                        pd[sl][u] = Vec<T>::load_raw(dy + ((long)b * HW + rn) * lddy + c * V);
+                    }
+                }
+            }
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int c = cb + mp.tpr * sl;
                 if (c < nchunks) {
-                    float f[UNR][V], d[UNR][V];
 #pragma unroll
                     for (int u = 0; u < UNR; ++u) {
                         const int rr = r + u * mp.rif;
                         if (rr < r1) {
-                            Vec<T>::load(x + ((long)b * HW + rr) * ldx + c * V, f[u]);
-                            Vec<T>::load(dy + ((long)b * HW + rr) * lddy + c * V, d[u]);
-                        } else {
+                            float f[V], d[V];
+                            Vec<T>::unpack(cx[sl][u], f);
+                            Vec<T>::unpack(cd[sl][u], d);
 #pragma unroll
-                            for (int e = 0; e < V; ++e) f[u][e] = d[u][e] = 0.f;
+                            for (int e = 0; e < V; ++e) {
+                                const float xh = (f[e] - mean[sl][e]) * rstd[sl][e];
+                                float dz = d[e];
+                                if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
+                                a1[sl][e] += dz;
+                                a2[sl][e] += dz * xh;
+                            }
                         }
                     }
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                        for (int e = 0; e < V; ++e) {
-                            const float xh = (f[u][e] - mean[sl][e]) * rstd[sl][e];
-                            float dz = d[u][e];
-                            if (silu) dz *= silu_grad_f(xh * gm[sl][e] + bt[sl][e]);
-                            a1[sl][e] += dz;
-                            a2[sl][e] += dz * xh;
-                        }
                 }
             }
         }
