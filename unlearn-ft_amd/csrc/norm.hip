@@ -695,47 +695,82 @@ int gn_bwd(const void* x, const void* dy, void* dx, const float* gamma, const fl
 // ------------------------------------------------------------------------------------------------ LayerNorm
 constexpr int LN_MAXS = 5;   // per-lane chunk slots: C <= 5*64*chunk
 
-template <typename T>
+// forward: a wave owns `rows_per_wave` consecutive rows.  gamma / beta stay in registers for all of them (16-byte loads, once per
+// wave: the first version re-read them element by element for every row - 16 scalar loads per lane and row against one 16-byte
+// load and one store of data, so the kernel was bound by VMEM instruction issue, 3.7 TB/s where a copy reaches 6.4) and the next
+// row's load is in flight while the current row is reduced and written (the two wave reductions make one row a latency chain).
+template <typename T, int SLOTS>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ stats, int M, int C, int ldx, int ldy,
-                                                    float eps) {
+                                                    float eps, int rows_per_wave) {
     constexpr int V = Vec<T>::N;
+    typedef typename Vec<T>::raw Raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
-    if (m >= M) return;
+    const int mbase = (blockIdx.x * 4 + wave) * rows_per_wave, mend = min(M, mbase + rows_per_wave);
+    if (mbase >= M) return;
     const int nchunks = C / V;
-    float f[LN_MAXS][V];
-    float sum = 0.f;
+    const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    Raw pre[SLOTS];
 #pragma unroll
-    for (int sl = 0; sl < LN_MAXS; ++sl) {
+    for (int sl = 0; sl < SLOTS; ++sl) {
         const int c = lane + 64 * sl;
-        if (c < nchunks) {
-            Vec<T>::load(x + (long)m * ldx + c * V, f[sl]);
+        if (c < nchunks) pre[sl] = Vec<T>::load_raw(x + (long)mbase * ldx + c * V);
+    }
+    float gm[SLOTS][V], bt[SLOTS][V];
 #pragma unroll
-            for (int e = 0; e < V; ++e) sum += f[sl][e];
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int c = lane + 64 * sl;
+        if (c < nchunks && vec_gb) {
+#pragma unroll
+            for (int e = 0; e < V; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + c * V + e), b4 = *reinterpret_cast<const float4*>(beta + c * V + e);
+                gm[sl][e] = g4.x; gm[sl][e + 1] = g4.y; gm[sl][e + 2] = g4.z; gm[sl][e + 3] = g4.w;
+                bt[sl][e] = b4.x; bt[sl][e + 1] = b4.y; bt[sl][e + 2] = b4.z; bt[sl][e + 3] = b4.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                gm[sl][e] = c < nchunks ? gamma[c * V + e] : 0.f;
+                bt[sl][e] = c < nchunks ? beta[c * V + e] : 0.f;
+            }
         }
     }
-    const float mean = wave_sum(sum) / C;
-    float sq = 0.f;
+    const float invC = 1.0f / C;
+    for (int m = mbase; m < mend; ++m) {
+        float f[SLOTS][V];
+        float sum = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < LN_MAXS; ++sl) {
-        const int c = lane + 64 * sl;
-        if (c < nchunks) {
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = lane + 64 * sl;
+            if (c < nchunks) {
+                Vec<T>::unpack(pre[sl], f[sl]);
+                if (m + 1 < mend) pre[sl] = Vec<T>::load_raw(x + (long)(m + 1) * ldx + c * V);
 #pragma unroll
-            for (int e = 0; e < V; ++e) { const float d = f[sl][e] - mean; sq += d * d; }
+                for (int e = 0; e < V; ++e) sum += f[sl][e];
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / C + eps);
-    if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
+        const float mean = wave_sum(sum) * invC;
+        float sq = 0.f;
 #pragma unroll
-    for (int sl = 0; sl < LN_MAXS; ++sl) {
-        const int c = lane + 64 * sl;
-        if (c < nchunks) {
-            float o[V];
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = lane + 64 * sl;
+            if (c < nchunks) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) o[e] = (f[sl][e] - mean) * rstd * gamma[c * V + e] + beta[c * V + e];
-            Vec<T>::store(y + (long)m * ldy + c * V, o);
+                for (int e = 0; e < V; ++e) { const float d = f[sl][e] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) * invC + eps);
+        if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int c = lane + 64 * sl;
+            if (c < nchunks) {
+                float o[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) o[e] = (f[sl][e] - mean) * rstd * gm[sl][e] + bt[sl][e];
+                Vec<T>::store(y + (long)m * ldy + c * V, o);
+            }
         }
     }
 }
@@ -850,8 +885,17 @@ int ln_fwd(const void* x, void* y, const float* gamma, const float* beta, float*
            float eps, hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || ldy % V || C / V > LN_MAXS * 64) return -1;
-    hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3((M + 3) / 4), dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, stats, M,
-                       C, ldx, ldy, eps);
+    int rpw = M / 8192;                              // rows per wave: 1 ... 8, >= ~2048 blocks of 4 waves (tools/ln_bench.py: 32 768 x 320
+    rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);         // rows take 13.6 / 12.2 / 11.6 / 14.6 us at 1 / 2 / 4 / 8 rows per wave)
+    const dim3 grid((M + 4 * rpw - 1) / (4 * rpw));
+    const int slots = (C / V + 63) / 64;
+#define PDMK_LNF(S) hipLaunchKernelGGL((ln_fwd_kernel<T, S>), grid, dim3(NT), 0, st, (const T*)x, (T*)y, gamma, beta, stats, M, \
+                                       C, ldx, ldy, eps, rpw)
+    if (slots == 1) PDMK_LNF(1);
+    else if (slots == 2) PDMK_LNF(2);
+    else if (slots == 3) PDMK_LNF(3);
+    else PDMK_LNF(5);
+#undef PDMK_LNF
     PDMK_CHECK_LAUNCH();
     return 0;
 }
