@@ -799,25 +799,47 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
     const int mbase = (blockIdx.x * 4 + wave) * rows_per_wave;
     const int mend = min(M, mbase + rows_per_wave);
     const float invC = 1.0f / C;
-    for (int m0 = mbase; m0 < mend; m0 += R) {
-        float xh[R][SLOTS][V], d[R][SLOTS][V], mean[R], rstd[R];
+    // register ping-pong: the next R rows (x, dy, their statistics) are requested before the current R rows are reduced - the two
+    // wave reductions per row otherwise leave the memory pipe idle (36.9 us for 32 768 x 320 against 6.7 for a copy)
+    typedef typename Vec<T>::raw Raw;
+    Raw px[R][SLOTS], pd[R][SLOTS];
+    float pm[R], pr[R];
+    auto fetch = [&](int m0) {
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const int m = min(m0 + q, mend - 1);          // clamp: duplicates of the last row are discarded below
-            mean[q] = stats[2 * (long)m];
-            rstd[q] = stats[2 * (long)m + 1];
+            pm[q] = stats[2 * (long)m];
+            pr[q] = stats[2 * (long)m + 1];
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int c = lane + 64 * sl;
                 if (c < nchunks) {
-                    Vec<T>::load(x + (long)m * ldx + c * V, xh[q][sl]);
-                    Vec<T>::load(dy + (long)m * lddy + c * V, d[q][sl]);
+                    px[q][sl] = Vec<T>::load_raw(x + (long)m * ldx + c * V);
+                    pd[q][sl] = Vec<T>::load_raw(dy + (long)m * lddy + c * V);
+                }
+            }
+        }
+    };
+    if (mbase < mend) fetch(mbase);
+    for (int m0 = mbase; m0 < mend; m0 += R) {
+        float xh[R][SLOTS][V], d[R][SLOTS][V], mean[R], rstd[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            mean[q] = pm[q];
+            rstd[q] = pr[q];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int c = lane + 64 * sl;
+                if (c < nchunks) {
+                    Vec<T>::unpack(px[q][sl], xh[q][sl]);
+                    Vec<T>::unpack(pd[q][sl], d[q][sl]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < V; ++e) xh[q][sl][e] = d[q][sl][e] = 0.f;
                 }
             }
         }
+        if (m0 + R < mend) fetch(m0 + R);
 #pragma unroll
         for (int q = 0; q < R; ++q) {
             const bool live = m0 + q < mend;
@@ -899,14 +921,20 @@ int ln_fwd(const void* x, void* y, const float* gamma, const float* beta, float*
     PDMK_CHECK_LAUNCH();
     return 0;
 }
+// rows per wave of the LayerNorm backward (about `blocks` blocks of 4 waves; also fixes the partial-slab count)
+static int ln_bwd_rpw(int M) {
+    // (tools/ln_bench.py, 32 768 x 320: 45 / 32 / 25.5 / 28 us at 2048 / 1024 / 512 / 256 blocks - the block's LDS combine and slab row
+    // are worth ~16 rows of streaming; 8192 x 640: 19 us at 4 rows per wave, 16.6 at 8)
+    int rpw = (M + 512 * 4 - 1) / (512 * 4);
+    return rpw < 8 ? 8 : (rpw > 64 ? 64 : rpw);
+}
 template <typename T>
 int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats, float* dgamma,
            float* dbeta, float* part, long part_elems, int M, int C, int ldx, int lddy, int lddx, int acc,
            hipStream_t st) {
     constexpr int V = Vec<T>::N;
     if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64) return -1;
-    int rpw = (M + 1024 * 4 - 1) / (1024 * 4);      // about 1024 blocks
-    rpw = rpw < 4 ? 4 : (rpw > 64 ? 64 : rpw);
+    const int rpw = ln_bwd_rpw(M);
     const int rows_per_blk = 4 * rpw;
     const dim3 grid((M + rows_per_blk - 1) / rows_per_blk);
     if (!part || (long)grid.x * 2 * C > part_elems) return -1;
@@ -986,8 +1014,7 @@ extern "C" int pdmk_groupnorm_bwd_partial_dims(int B, int HW, int C, int G, int 
 }
 extern "C" int pdmk_layernorm_bwd_partial_dims(int M, int C, int32_t* nblk, int32_t* n) {
     if (!nblk || !n || M <= 0 || C <= 0) return -1;
-    int rpw = (M + 1024 * 4 - 1) / (1024 * 4);
-    rpw = rpw < 4 ? 4 : (rpw > 64 ? 64 : rpw);
+    const int rpw = ln_bwd_rpw(M);
     *nblk = (M + 4 * rpw - 1) / (4 * rpw);
     *n = C;
     return 0;
