@@ -1269,3 +1269,44 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
     with pytest.raises(k.PdmkError):
         k.gemm(rnd((96, 32), dev, dt), rnd((64, 32), dev, dt), y, 96, 64, 32, 32, 32, 64, rows_per_b=48,
                colstat=(torch.zeros(2, 4, 64, device=dev, dtype=torch.int64), 0))
+
+
+@pytest.mark.parametrize("dn", ["bf16", "f32"])
+def test_transpose_tiles_vector_and_scalar_paths(dev, dn):
+    """pdmk_transpose_tiles (the dgrad weight copies, params.py refresh_wt): 64x64-tile table records over strided sources and
+    destinations - the 16-byte path (offsets, row strides and extents in whole chunks; ragged last tiles in both directions), the
+    element-wise path (odd strides / offsets) and a conv-style job (src [co][9][ci] tap slice -> dst [ci][9][co] flipped tap)."""
+    import numpy as np
+    from pdm import _pdmk as k
+    torch.manual_seed(3)
+    dt = DT[dn]
+
+    def table(jobs):
+        recs = []
+        for so, do, rows, cols, sld, dld in jobs:
+            rr, cc = np.meshgrid(np.arange(0, rows, 64), np.arange(0, cols, 64), indexing="ij")
+            t = np.zeros((rr.size, 12), dtype=np.int64)
+            t[:, 0], t[:, 2] = so, do
+            t[:, 4], t[:, 5], t[:, 6], t[:, 7] = rows, cols, sld, dld
+            t[:, 8], t[:, 9] = rr.ravel(), cc.ravel()
+            recs.append(t)
+        tab = np.concatenate(recs, 0).astype(np.int32)
+        return torch.from_numpy(tab).to(dev), tab.shape[0]
+
+    for rows, cols, sld, dld, so, do in ((200, 136, 136, 200, 0, 0), (64, 64, 64, 64, 0, 0), (328, 72, 80, 336, 16, 64),
+                                         (50, 37, 37, 50, 0, 0), (72, 40, 41, 72, 3, 0), (130, 320, 320, 136, 8, 24)):
+        src = rnd((so + rows * sld + 8,), dev, dt)
+        dst = torch.full((do + cols * dld + 8,), 7.0, device=dev, dtype=dt)
+        tab, n = table([(so, do, rows, cols, sld, dld)])
+        k.transpose_tiles(src, dst, tab, n)
+        s2 = src[so:so + rows * sld].view(rows, sld)[:, :cols]
+        d2 = dst[do:do + cols * dld].view(cols, dld)
+        assert torch.equal(d2[:, :rows], s2.t()), (rows, cols, sld, dld, so, do)
+        assert (d2[:, rows:] == 7.0).all() and (dst[:do] == 7.0).all()
+    # conv weight: src [co][9][ci] -> dst [ci][9 flipped][co], nine jobs in one launch
+    co, ci = 96, 40
+    w = rnd((co, 9, ci), dev, dt)
+    wt = torch.zeros(ci, 9, co, device=dev, dtype=dt)
+    tab, n = table([(t_ * ci, (8 - t_) * co, co, ci, 9 * ci, 9 * co) for t_ in range(9)])
+    k.transpose_tiles(w, wt, tab, n)
+    assert torch.equal(wt, w.flip(1).permute(2, 1, 0).contiguous())
