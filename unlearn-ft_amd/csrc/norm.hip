@@ -200,6 +200,22 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     // kernel streamed at 2.5 TB/s where a plain copy of the same tensor reaches 6.4, tools/gn_bench.py).
     const bool active = ro < mp.rif;
     const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
+    // (the statistics' own loads are the very first: loads return in issue order, so behind the row sweep they would wait for it)
+    long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+    if (nblk < 0 && (tid >> 2) < G) {
+        // epilogue statistics (pdmk_gemm_args.colstat): `part` = this tensor's first column of the [B][4][cs_ld] per-(image, column)
+        // fixed-point sums (two limbs each); group g = its gs columns.  4 threads per group (G <= 64): thread (g, p) adds the limbs of
+        // columns p, p + 4, ... in registers, the partners are folded with two shuffles below.  Exact integer sums, no atomics
+        // (LDS atomics here put 40 same-address adds of one group into one wave instruction: 8 us per block)
+        const long long* cg = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld + (tid >> 2) * gs;
+#pragma unroll 4
+        for (int j = tid & 3; j < gs; j += 4) {
+            l0 += cg[j];
+            h0 += cg[cs_ld + j];
+            l1 += cg[2 * cs_ld + j];
+            h1 += cg[3 * cs_ld + j];
+        }
+    }
     float gmv[SLOTS][V], btv[SLOTS][V];
     Raw pre[SLOTS][UNR];
 #pragma unroll
@@ -228,24 +244,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
         }
     }
     if (nblk < 0) {
-        // statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): `part` = this tensor's first column of the
-        // [B][4][cs_ld] per-(image, column) fixed-point sums (two limbs each); group g = its gs columns.
-        // 256 / 64 = 4 threads per group (G <= 64): thread (g, p) adds the limbs of columns p, p + 4, ... of its group in
-        // registers (independent loads, all in flight), the four partners are folded with two shuffles.  Exact integer sums, no
-        // atomics: LDS atomics here put 40 same-address adds of one group into one wave instruction - 8 us per block.
-        const long long* c0 = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld;
         const int g = tid >> 2, pth = tid & 3;
-        long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;
-        if (g < G) {
-            const long long* cg = c0 + g * gs;
-#pragma unroll 4
-            for (int j = pth; j < gs; j += 4) {
-                l0 += cg[j];
-                h0 += cg[cs_ld + j];
-                l1 += cg[2 * cs_ld + j];
-                h1 += cg[3 * cs_ld + j];
-            }
-        }
 #pragma unroll
         for (int m = 1; m < 4; m <<= 1) {
             l0 += __shfl_xor(l0, m, 64);
