@@ -531,7 +531,15 @@ __global__ void splitk_finish_kernel(const float* __restrict__ ws, T* __restrict
         const long m = i / nc;
         const int n = (int)(i - m * nc) * 4;
         float4 w = *reinterpret_cast<const float4*>(ws + m * N + n);
-        for (int sl = 1; sl < nslab; ++sl) {                       // split-K slabs [nslab][M][N], added in a fixed order
+        int sl = 1;
+        for (; sl + 3 <= nslab; sl += 3) {                         // split-K slabs [nslab][M][N], added in a fixed order; three
+            const float4 u0 = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * N + n);          // loads in flight
+            const float4 u1 = *reinterpret_cast<const float4*>(ws + ((long)(sl + 1) * M + m) * N + n);
+            const float4 u2 = *reinterpret_cast<const float4*>(ws + ((long)(sl + 2) * M + m) * N + n);
+            w.x = ((w.x + u0.x) + u1.x) + u2.x; w.y = ((w.y + u0.y) + u1.y) + u2.y;
+            w.z = ((w.z + u0.z) + u1.z) + u2.z; w.w = ((w.w + u0.w) + u1.w) + u2.w;
+        }
+        for (; sl < nslab; ++sl) {
             const float4 u = *reinterpret_cast<const float4*>(ws + ((long)sl * M + m) * N + n);
             w.x += u.x; w.y += u.y; w.z += u.z; w.w += u.w;
         }
@@ -742,7 +750,16 @@ __global__ void splitk_finish_group_kernel(SlabGroup gr) {
     float4* dst = reinterpret_cast<float4*>(it.dst);
     for (long i = blockIdx.x * (long)NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
         float4 a = dst[i];
-        for (int s = 0; s < it.nslab; ++s) {
+        int s = 0;
+        for (; s + 4 <= it.nslab; s += 4) {           // four slabs' loads in flight; the sum order stays slab 0, 1, 2, ... (fixed)
+            const float4 v0 = ws[(long)s * n4 + i], v1 = ws[(long)(s + 1) * n4 + i], v2 = ws[(long)(s + 2) * n4 + i],
+                         v3 = ws[(long)(s + 3) * n4 + i];
+            a.x = (((a.x + v0.x) + v1.x) + v2.x) + v3.x;
+            a.y = (((a.y + v0.y) + v1.y) + v2.y) + v3.y;
+            a.z = (((a.z + v0.z) + v1.z) + v2.z) + v3.z;
+            a.w = (((a.w + v0.w) + v1.w) + v2.w) + v3.w;
+        }
+        for (; s < it.nslab; ++s) {
             const float4 v = ws[(long)s * n4 + i];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
