@@ -183,6 +183,7 @@ class UNetEngine:
         skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * Kp * 4 + 512 <= 65536
         skinny_dgrad = skinny and (8 if M <= 8 else 16) * Np * 4 + 512 <= 65536
         gl = None
+        acc, acc_ok = None, False       # GroupNorm statistics out of this GEMM's epilogue (cs): the accumulator slice, and whether it was fed
         if geglu:
             assert residual is None and out is None and not out_f32
             gl = self._empty(M, Np // 2)
@@ -214,7 +215,7 @@ class UNetEngine:
         if geglu and not fused:
             k.geglu_fwd(y, gl, M, Np // 2, _ld(y), Np // 2, layout=1)
         out = Act(y)
-        if cs is not None and not (geglu or skinny) and locals().get("acc_ok"):
+        if acc_ok:
             out.cs = (acc[0], acc[1], Np)
         if self.train:
             def bwd():
@@ -290,7 +291,7 @@ class UNetEngine:
         assert tuple(y.shape) == (M, Cop)
         if (mode == 2 and getattr(self, 'up2', False) and rowvec is None and residual is None and
                 k.conv_up2_supported(B, Hi, Wi, Cip, Cop, self.dtype)):
-            return self._conv_up2(x, key, B, Hi, Wi, bias, y, e, ((True if out is not None else None) if cs else False)), Ho, Wo
+            return self._conv_up2(x, key, B, Hi, Wi, bias, y, e, cs and ("view" if out is not None else "own")), Ho, Wo
         acc = self._cs_for(y, B, Ho * Wo, M, Cop, view=out is not None) if cs else None   # a GroupNorm reads this output next
         acc_ok = k.gemm_auto(x.t, P.wv(key + ".weight"), y, M, Cop, 9 * Cip, 0, 9 * Cip, _ld(y), a_mode=k.A_CONV,
                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(x.t)), bias=P.p(bias),
@@ -355,9 +356,9 @@ class UNetEngine:
         wp, wpt = P.up2_weights(key)
         lmacs = 4 * Ml * e.logical[0] * e.logical[1] * 4           # executed multiply-accumulates (the 3x3 form: 9 / 4 of it)
         geo = lambda m, ci, ld: (B, Hi, Wi, ci, Hi, Wi, m, ld)
-        # cs: None = y is a fresh tensor, True = a concat view (the four phases add their column sums to that buffer's
-        # GroupNorm accumulator; rows are counted on the low-resolution grid each phase enumerates)
-        acc = self._cs_for(y, B, Hi * Wi, Ml, Cop, view=cs is True) if cs is not False else None
+        # cs: False = no GroupNorm reads this output; "own" = y is a fresh tensor; "view" = y is a concat view (the four phases add
+        # their column sums to that buffer's GroupNorm accumulator; rows are counted on the low-resolution grid a phase enumerates)
+        acc = self._cs_for(y, B, Hi * Wi, Ml, Cop, view=cs == "view") if cs else None
         with k.Recorder() as r:
             for p_ in range(4):
                 k.gemm(x.t, wp[p_], y, Ml, Cop, 4 * Cip, 0, 4 * Cip, _ld(y), a_mode=k.A_CONV, conv=geo(5 + p_, Cip, _ld(x.t)),
