@@ -207,6 +207,11 @@ int pdmk_plan_export(const char* path);
 int pdmk_plan_import(const char* path);
 int pdmk_plan_size(void);
 int pdmk_plan_clear(void);
+/* Debug aid for the exception above (no reference counterpart): with PDMK_DEBUG_SCRATCH=1 in the environment every tuning pass
+ * re-allocates its scratch at exactly the size it computed, with a 1 MiB band of 0xA5 behind it, and checks the band after the
+ * timing launches; pdmk_debug_scratch_violations returns how many passes found it overwritten (0 when the mode is off).  The
+ * regression guard of round 3's tuner overrun (forward phase convs store 4 M rows). */
+int pdmk_debug_scratch_violations(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC.  Replaces F.group_norm + F.silu at blocks.py:318-319, 348+371,

@@ -10,6 +10,9 @@
 import torch
 import torch.nn.functional as F
 
+import contextlib
+
+from . import unet as _unet
 from .unet import unet_forward
 
 BLOCK_KEYS = ("d0", "d1", "d2", "d3", "m", "u0", "u1", "u2", "u3")
@@ -92,10 +95,15 @@ class _mixed:
     """`--mixed_precision bf16` as accelerate applies it to the reference trainer (trainer.py:516-527, 2730-2733; SURVEY
     Appendix B.11): the frozen teacher's weights are CAST to bf16, the student keeps fp32 master weights and its forward runs
     under torch.autocast(bfloat16) (here the CPU autocast: conv / linear / matmul in bf16, the loss heads on what comes out
-    of them - H1/H2 upcast with .float(), H3/H4 do not).  mixed=False: plain fp32."""
+    of them - H1/H2 upcast with .float(), H3/H4 do not).  mixed=False: plain fp32.
+    mixed="cuda": the same, with CUDA autocast's op policy where it differs from the CPU autocast's (unet.FP32_NORMS:
+    group_norm / layer_norm upcast to fp32, attention as the fused SDPA computes it) - a second, equally valid bf16
+    evaluation of the same step; the two differ from each other by as much as either differs from fp32, which is what the
+    curve test uses to size its bound."""
 
     def __init__(self, on):
-        self.on = on
+        self.on = bool(on)
+        self.cuda_policy = on == "cuda"
 
     def teacher_sd(self, sd):
         if not self.on:
@@ -105,8 +113,15 @@ class _mixed:
             _mixed._cache = {"key": key, "sd": {k: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k, v in sd.items()}}
         return _mixed._cache["sd"]
 
+    @contextlib.contextmanager
     def ctx(self):
-        return torch.autocast("cpu", dtype=torch.bfloat16) if self.on else torch.autocast("cpu", enabled=False)
+        prev = _unet.FP32_NORMS
+        _unet.FP32_NORMS = self.cuda_policy
+        try:
+            with (torch.autocast("cpu", dtype=torch.bfloat16) if self.on else torch.autocast("cpu", enabled=False)):
+                yield
+        finally:
+            _unet.FP32_NORMS = prev
 
     _cache = {}
 

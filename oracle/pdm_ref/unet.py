@@ -16,6 +16,26 @@ from .arch import block_layout
 from .config import UNetConfig
 
 
+# Mixed-precision policy of the norms / softmax (set by step._mixed): False = the op runs in its input dtype (what torch's CPU
+# autocast does: group_norm / layer_norm / softmax of a bf16 tensor stay bf16); True = CUDA autocast's policy, which the reference
+# trains under (trainer.py:516-527 + accelerate): group_norm / layer_norm are on the fp32 list (inputs upcast, fp32 result that the
+# next conv / linear casts to bf16 once), and the fused F.scaled_dot_product_attention (blocks.py:257-277) keeps QK^T and the
+# softmax in fp32, rounding only P to bf16 for the PV product.
+FP32_NORMS = False
+
+
+def _gn(x, groups, w, b, eps):
+    if FP32_NORMS and x.dtype != torch.float32:
+        return F.group_norm(x.float(), groups, w.float(), b.float(), eps)
+    return F.group_norm(x, groups, w, b, eps)
+
+
+def _ln(x, shape, w, b, eps):
+    if FP32_NORMS and x.dtype != torch.float32:
+        return F.layer_norm(x.float(), shape, w.float(), b.float(), eps)
+    return F.layer_norm(x, shape, w, b, eps)
+
+
 def timestep_embedding(t, dim):
     half = dim // 2
     freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
@@ -24,12 +44,12 @@ def timestep_embedding(t, dim):
 
 
 def resblock(sd, p, x, temb, groups1, groups2, eps=1e-5):
-    h = F.group_norm(x, groups1, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
+    h = _gn(x, groups1, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
     h = F.silu(h)
     h = F.conv2d(h, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
     tp = F.linear(F.silu(temb), sd[p + ".time_emb_proj.weight"], sd[p + ".time_emb_proj.bias"])
     h = h + tp[:, :, None, None]
-    h = F.group_norm(h, groups2, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
+    h = _gn(h, groups2, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
     h = F.silu(h)
     h = F.conv2d(h, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in sd:
@@ -43,8 +63,14 @@ def attention(sd, p, x, ctx, heads, head_dim):
     q = F.linear(x, sd[p + ".to_q.weight"]).view(B, N, heads, head_dim).transpose(1, 2)
     k = F.linear(src, sd[p + ".to_k.weight"]).view(B, -1, heads, head_dim).transpose(1, 2)
     v = F.linear(src, sd[p + ".to_v.weight"]).view(B, -1, heads, head_dim).transpose(1, 2)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (head_dim ** -0.5)
-    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    if FP32_NORMS and q.dtype != torch.float32:      # fused SDPA numerics: fp32 scores and softmax, P rounded once
+        with torch.autocast("cpu", enabled=False):
+            s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (head_dim ** -0.5)
+            pr = torch.softmax(s, dim=-1).to(v.dtype)
+            o = torch.matmul(pr, v)
+    else:
+        s = torch.matmul(q, k.transpose(-1, -2)) * (head_dim ** -0.5)
+        o = torch.matmul(torch.softmax(s, dim=-1), v)
     o = o.transpose(1, 2).reshape(B, N, heads * head_dim)
     return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
 
@@ -52,15 +78,15 @@ def attention(sd, p, x, ctx, heads, head_dim):
 def transformer2d(sd, p, x, ctx, heads1, heads2, head_dim, groups):
     B, C, H, W = x.shape
     res = x
-    h = F.group_norm(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    h = _gn(x, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
     h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
     h = F.linear(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
     t = p + ".transformer_blocks.0"
-    n = F.layer_norm(h, (C,), sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], 1e-5)
+    n = _ln(h, (C,), sd[t + ".norm1.weight"], sd[t + ".norm1.bias"], 1e-5)
     h = attention(sd, t + ".attn1", n, None, heads1, head_dim) + h
-    n = F.layer_norm(h, (C,), sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], 1e-5)
+    n = _ln(h, (C,), sd[t + ".norm2.weight"], sd[t + ".norm2.bias"], 1e-5)
     h = attention(sd, t + ".attn2", n, ctx, heads2, head_dim) + h
-    n = F.layer_norm(h, (C,), sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], 1e-5)
+    n = _ln(h, (C,), sd[t + ".norm3.weight"], sd[t + ".norm3.bias"], 1e-5)
     f = F.linear(n, sd[t + ".ff.net.0.proj.weight"], sd[t + ".ff.net.0.proj.bias"])
     a, g = f.chunk(2, dim=-1)
     f = a * F.gelu(g)
@@ -127,7 +153,7 @@ def unet_forward(sd, cfg: UNetConfig, info, sample, timesteps, ehs, acts=None):
             if acts is not None:
                 acts[f"u{b['idx']}"] = h
     assert not skips
-    h = F.group_norm(h, G, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], 1e-5)
+    h = _gn(h, G, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], 1e-5)
     h = F.silu(h)
     return F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
 

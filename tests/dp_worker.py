@@ -105,12 +105,67 @@ def run(mode, world, rank, out=None):
     return res
 
 
+def run_comm(world, rank, out):
+    """RCCL with world > 1, one device per rank (needs >= world GPUs): the library communicator's reduce-scatter + all-gather
+    (in place, RCCL's documented placement) and GradReducer's torch.distributed rs_ag branch (scratch share) against a plain
+    all-reduce of the same buckets - bit-equal is not promised by RCCL across algorithms, so sums of small integers are used,
+    which every summation order gives exactly."""
+    from pdm import _pdmk as k
+    from pdm.training.bilevel import GradReducer
+    dev = torch.device(DEV())
+    n = 8 * 1031
+    x = ((torch.arange(n, device=dev) % 251) + 1).float() * (rank + 1)
+    want = ((torch.arange(n, device=dev) % 251) + 1).float() * sum(r + 1 for r in range(world))
+    box = [k.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = k.Comm(box[0], rank, world)
+    assert (comm.world_size(), comm.rank_id()) == (world, rank)
+    a = x.clone()
+    comm.all_reduce_sum_(a)
+    m = n - n % world
+    b = x[:m].clone()
+    comm.reduce_scatter_sum_(b)
+    per = m // world
+    torch.cuda.synchronize()
+    assert torch.equal(b[rank * per:(rank + 1) * per], want[rank * per:(rank + 1) * per])
+    comm.all_gather_(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, want) and torch.equal(b, want[:m])
+    comm.close()
+    for mode, native in (("rs_ag", False), ("rs_ag", True), ("allreduce", True)):
+        os.environ.pop("PDMK_COMM", None)
+        if native:
+            os.environ["PDMK_COMM"] = "native"
+
+        class Store:
+            total = n
+            master = torch.zeros(n, device=dev)
+            grad = x.clone()
+        red = GradReducer(Store, bucket_mb=1, mode=mode)
+        red.bucket = 1001
+        red.begin()
+        red.ready_down_to(4000)
+        red.ready_down_to(0)
+        assert red.finish() == 1.0 / world
+        torch.cuda.synchronize()
+        assert torch.equal(Store.grad, want), (mode, native)
+    if out and rank == 0:
+        torch.save({"ok": True}, out)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True, choices=["eager", "graph"])
+    ap.add_argument("--mode", required=True, choices=["eager", "graph", "comm"])
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if a.mode == "comm":
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        run_comm(world, rank, a.out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # one device per rank when the box has them (LOCAL_RANK -> set_device, as bench.py / Trainer do); on a one-GPU box both
     # ranks share cuda:0 (RCCL refuses that, gloo does not)
     torch.cuda.set_device(DEV_INDEX())

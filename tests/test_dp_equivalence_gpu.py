@@ -69,3 +69,15 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(dev, tmp_path, mode, dp_m
     scale = ref["master"].abs().max().item()
     assert (got["master"] - ref["master"]).abs().max().item() <= max(1e-5 * scale, 8 * dp_worker.UPPER_LR), \
         (got["master"] - ref["master"]).abs().max().item()
+
+
+def test_rccl_reduce_scatter_allgather_equal_allreduce_two_devices(dev, tmp_path):
+    """Needs two GPUs (skipped on the one-GPU boxes this suite normally runs on): two ranks, one device each, `nccl` backend =
+    RCCL.  pdmk_comm_reduce_scatter_sum_f32 + pdmk_comm_allgather_f32 (in place) and GradReducer's rs_ag mode over
+    torch.distributed and over the native communicator all reproduce the all-reduce's sums (tests/dp_worker.py::run_comm).
+    Reference: the DDP gradient exchange, pdm/training/trainer.py:117-129, 2782, 2808."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with world > 1 needs one device per rank (one-GPU box)")
+    out = str(tmp_path / "comm.pt")
+    _spawn("comm", 2, out)
+    assert torch.load(out)["ok"]

@@ -61,6 +61,108 @@ def _rs_ag_body(red, Store, rank, world, q):
     dist.destroy_process_group()
 
 
+def _overlap(a, b):
+    lo_a, lo_b = a.data_ptr(), b.data_ptr()
+    return lo_a < lo_b + b.numel() * b.element_size() and lo_b < lo_a + a.numel() * a.element_size()
+
+
+def _worker_world8(rank, world, port, q, case):
+    """One rank of the world-size-8 arithmetic checks (the target job: one node of 8 MI355X).  case = (mode, bucket elements,
+    branch): branch "gloo" = GradReducer's gloo emulation, "pg" = its torch.distributed reduce_scatter_tensor /
+    all_gather_into_tensor branch (what runs over RCCL), exercised here through stand-ins built on gloo's all_reduce /
+    all_gather that also REFUSE an output aliasing the input."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from pdm.training.bilevel import GradReducer
+        mode, bucket, branch = case
+        N = 1003                                              # prime-ish arena: ragged head in every configuration
+
+        class Store:
+            total = N
+            master = torch.zeros(N)
+            grad = (torch.arange(N, dtype=torch.float32) % 97 + 1) * (rank + 1)
+        red = GradReducer(Store, bucket_mb=1, mode=mode)
+        red.bucket = bucket
+        calls = {"rs": 0, "ag": 0}
+        if branch == "pg":
+            red.backend = "nccl"                              # take the reduce_scatter_tensor / all_gather_into_tensor branch
+
+            def rs(out, inp, op=None):
+                assert not _overlap(out, inp), "reduce_scatter_tensor output aliases its input"
+                assert inp.numel() == world * out.numel()
+                tmp = inp.clone()
+                dist.all_reduce(tmp)
+                out.copy_(tmp[rank * out.numel():(rank + 1) * out.numel()])
+                calls["rs"] += 1
+
+            def ag(out, inp):
+                assert not _overlap(out, inp), "all_gather_into_tensor output aliases its input"
+                assert out.numel() == world * inp.numel()
+                parts = [torch.empty_like(inp) for _ in range(world)]
+                dist.all_gather(parts, inp.contiguous())
+                out.copy_(torch.cat(parts))
+                calls["ag"] += 1
+            dist.reduce_scatter_tensor, dist.all_gather_into_tensor = rs, ag
+        red.begin()
+        launched = []
+        orig = red._launch
+        red._launch = lambda lo, hi: (launched.append((lo, hi)), orig(lo, hi))[1]
+        for lo in (900, 512, 511, 64, 0):                     # the backward tape reports these offsets as final, in order
+            red.ready_down_to(lo)
+        scale = red.finish()
+        # every element reduced exactly once, buckets contiguous from the tail, nothing left
+        assert launched and launched[0][1] == N and launched[-1][0] == 0, launched
+        assert all(a[0] == b[1] for a, b in zip(launched, launched[1:])), launched
+        assert all(hi - lo == bucket for lo, hi in launched[:-1]) and launched[-1][1] - launched[-1][0] <= max(bucket, N), launched
+        expect_coll = 0
+        for lo, hi in launched:
+            n = hi - lo
+            if mode == "allreduce":
+                expect_coll += 1
+            else:
+                expect_coll += (2 if n - n % world else 0) + (1 if n % world else 0)
+        assert red.n_collectives == expect_coll, (red.n_collectives, expect_coll, launched)
+        if branch == "pg":
+            bodies = sum(1 for lo, hi in launched if (hi - lo) - (hi - lo) % world)
+            assert calls == {"rs": bodies, "ag": bodies}, (calls, bodies)
+        expect = (torch.arange(N, dtype=torch.float32) % 97 + 1) * sum(r + 1 for r in range(world))
+        q.put((rank, bool(torch.equal(Store.grad, expect)) and scale == 1.0 / world, case))
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, False, repr(e)))
+        raise
+
+
+def _run_world8(case, port_base):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = port_base + os.getpid() % 1000
+    ps = [ctx.Process(target=_worker_world8, args=(r, 8, port, q, case)) for r in range(8)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=180) for _ in ps]
+    [p.join(60) for p in ps]
+    assert all(ok for _, ok, _ in res), res
+    assert all(p.exitcode == 0 for p in ps)
+
+
+def test_bucket_share_tail_arithmetic_world8_gloo():
+    """World size 8 (the job the metric is quoted on): tail-first buckets with a ragged head, for an odd bucket (255: share
+    body 248 + tail 7), a bucket SMALLER than the world (5: no share body at all, the tail all-reduce carries it), a bucket
+    the world divides (64: no tail) and one bucket larger than the arena; both exchange modes; sums, bucket order, contiguity
+    and the number of collectives."""
+    for i, case in enumerate([("rs_ag", 255, "gloo"), ("rs_ag", 5, "gloo"), ("rs_ag", 64, "gloo"), ("allreduce", 255, "gloo"),
+                              ("rs_ag", 4096, "gloo")]):
+        _run_world8(case, 31512 + 7 * i)
+
+
+def test_rs_ag_process_group_branch_never_aliases_world8():
+    """The branch that runs over RCCL (dist.reduce_scatter_tensor / all_gather_into_tensor): its share is a scratch buffer, never
+    a slice of the bucket - checked with stand-ins that refuse aliased arguments - and the sums equal the all-reduce's."""
+    for i, case in enumerate([("rs_ag", 255, "pg"), ("rs_ag", 64, "pg")]):
+        _run_world8(case, 32512 + 7 * i)
+
+
 def test_bucketed_reduce_scatter_allgather_world2_gloo():
     """PDMK_DP_MODE=rs_ag: every bucket as reduce-scatter + all-gather of `world` equal shares plus an all-reduce of the
     (n mod world) tail - the bucket / share arithmetic of SURVEY 5 / 8e, over gloo (share-wise reduce + broadcast, the same

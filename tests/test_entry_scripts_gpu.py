@@ -1,0 +1,221 @@
+"""The three entry scripts end to end: `scripts/aptp/{finetune,bilevel_finetune,bilevel_finetune_nudity}.py::main()` over a YAML
+file with the key tree of the reference's shipped recipes (configs/baselines/sd-2-1_coco_aptp_both_512_bilevel.yaml:1-135,
+read by scripts/aptp/bilevel_finetune.py:19-41: argparse -> load -> `config.update(vars(args))` -> Trainer(config).train()).
+
+The YAML below is written as TEXT, the way the reference's files are: `1e-6`, `5e-6` and `1e-08` have no decimal point, so
+PyYAML (YAML 1.1 float grammar) hands them over as STRINGS - the trainer must cast them; keys this build does not use
+(hf_hub, report_to, dataloader options, prompts ...) must be accepted and ignored; `checkpoint_steps` sits under `training`
+(not `training.logging`) and `upper_data.style` is a list, as shipped.
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPTS = os.path.join(ROOT, "unlearn-ft_amd", "scripts", "aptp")
+
+YAML = """\
+model:
+  prediction_model:
+    pretrained_model_name_or_path: stabilityai/stable-unet-2-1
+    input_perturbation: 0.0
+    revision: null
+    resolution: 128
+    use_ema: false
+    noise_offset: 0.0
+    prediction_type: v_prediction
+    max_scheduler_steps: null
+    unet_down_blocks:
+      - CrossAttnDownBlock2DHalfGated
+      - CrossAttnDownBlock2DHalfGated
+      - CrossAttnDownBlock2DHalfGated
+      - DownBlock2DHalfGated
+
+    unet_mid_block: UNetMidBlock2DCrossAttnWidthGated
+
+    unet_up_blocks:
+      - UpBlock2DHalfGated
+      - CrossAttnUpBlock2DHalfGated
+      - CrossAttnUpBlock2DHalfGated
+      - CrossAttnUpBlock2DHalfGated
+
+    gated_ff: true
+    ff_gate_width: 32
+
+data:
+  dataset_name: null
+  data_files: null
+  dataset_config_name: null
+  data_dir: "/path/to/dataset"
+  max_train_samples: null
+  max_validation_samples: 1000
+  year: 2017
+  filter_dataset: false
+
+  image_column: "image"
+  caption_column: "caption"
+  prompts:
+  - "Water Lilies by Claude Monet"
+  - "Water Lilies"
+  max_generated_samples: 4
+  dataloader:
+    dataloader_num_workers: 0
+    train_batch_size: 2
+    validation_batch_size: 1
+    image_generation_batch_size: 1
+    center_crop: false
+    random_flip: true
+
+upper_data:
+  dataset_name: "rezashkv/controlled_distillation"
+  data_files: null
+  dataset_config_name: null
+  data_dir: null
+  max_train_samples: null
+  max_validation_samples: null
+  year: null
+  filter_dataset: false
+  style:
+  - "Claude Monet"
+
+  image_column: "image"
+  caption_column: "caption"
+
+training:
+  num_train_epochs: null
+  max_train_steps: 3
+  validation_steps: 1000
+  image_logging_steps: 1000
+  checkpoint_steps: 2
+  num_inference_steps: 10 # number of scheduler steps to run for image generation
+
+  upper_step_freq: 2
+
+  mixed_precision: null
+  gradient_accumulation_steps: 1
+  gradient_checkpointing: false
+  local_rank: -1
+  allow_tf32: false
+  enable_xformers_memory_efficient_attention: false
+
+  losses:
+    diffusion_loss:
+      snr_gamma: 5.0
+      weight: 1.0
+      upper_weight: 0.0
+
+    distillation_loss:
+      weight: 2.0
+      upper_weight: 1.0
+
+    block_loss:
+      weight: 0.1
+      upper_weight: 0.0
+
+  optim:
+    prediction_model_learning_rate: 1e-6
+    prediction_model_weight_decay: 0.00
+
+    prediction_model_upper_learning_rate: 5e-6
+
+    optimizer: "adamw"
+    use_8bit_adam: false
+    adam_beta1: 0.9
+    adam_beta2: 0.999
+    adam_epsilon: 1e-08
+
+    scale_lr: false
+    lr_scheduler: "constant_with_warmup" # see pdm.utils.arg_utils for available options
+    lr_warmup_steps: 1
+
+  hf_hub:
+    push_to_hub: false
+    hub_token: null
+    hub_model_id: null
+
+  logging:
+    logging_dir: "@LOGDIR@"
+
+    report_to: "wandb"
+    tracker_project_name: "diffusion-pruning"
+    wandb_log_dir: "path/to/wandb"
+
+    checkpoints_total_limit: null
+    auto_checkpoint_step: false
+    resume_from_checkpoint: latest # or null
+"""
+
+
+def _write(tmp_path):
+    path = tmp_path / "recipe.yaml"
+    path.write_text(YAML.replace("@LOGDIR@", str(tmp_path / "logs")))
+    return str(path)
+
+
+def test_reference_yaml_numbers_without_a_decimal_point_arrive_as_strings(tmp_path):
+    """CPU: what the loader hands the trainer for the shipped recipes' `1e-6` / `5e-6` / `1e-08` (strings), and that the overlay
+    of the flat CLI namespace lands at the root of the tree (scripts/aptp/bilevel_finetune.py:23-25)."""
+    from pdm.utils.arg_utils import parse_args
+    from pdm.utils.config import load_config
+    cfg = load_config(_write(tmp_path))
+    o = cfg.training.optim
+    assert (o.prediction_model_learning_rate, o.prediction_model_upper_learning_rate, o.adam_epsilon) == ("1e-6", "5e-6", "1e-08")
+    assert [float(o[k_]) for k_ in ("prediction_model_learning_rate", "prediction_model_upper_learning_rate", "adam_epsilon")] == \
+        [1e-6, 5e-6, 1e-8]
+    assert isinstance(o.adam_beta1, float) and cfg.training.checkpoint_steps == 2 and cfg.upper_data.style == ["Claude Monet"]
+    args = parse_args(["--base_config_path", "x.yaml", "--pruning_ckpt_dir", "/ckpt", "--expert_id", "3", "--mixed_precision", "bf16",
+                       "--cache_dir", "/c", "--wandb_run_name", "run"])
+    cfg.update(vars(args))
+    assert cfg.pruning_ckpt_dir == "/ckpt" and cfg.expert_id == 3 and cfg.mixed_precision == "bf16" and cfg.seed == 43
+    assert cfg.training.mixed_precision is None and cfg.model.prediction_model.resolution == 128
+
+
+def _main_of(script):
+    spec = importlib.util.spec_from_file_location("entry_" + script, os.path.join(SCRIPTS, script + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.main
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("script,upper", [("finetune", False), ("bilevel_finetune", True), ("bilevel_finetune_nudity", True)])
+def test_entry_script_main_runs_three_steps_over_the_reference_key_tree(dev, tmp_path, monkeypatch, script, upper):
+    """`main()` of each entry script: 3 synthetic steps of the tiny topology from the YAML above; the metrics file has the
+    reference's keys (trainer.py:2819-2834), the learning rates are the YAML's string-typed values after the 1-step warm-up,
+    the upper step fires at (global_step + 1) % upper_step_freq == 0 for the bilevel classes only, and the checkpoint
+    directories have accelerate's layout (trainer.py:452-477, 2863-2869)."""
+    yaml_path = _write(tmp_path)
+    monkeypatch.setattr(sys, "argv", [script + ".py", "--base_config_path", yaml_path, "--synthetic", "--tiny",
+                                      "--mixed_precision", "bf16", "--keep_ratio", "0.7", "--cache_dir", str(tmp_path / "cache"),
+                                      "--wandb_run_name", "t"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    _main_of(script)()
+    torch.cuda.synchronize()
+    logs = tmp_path / "logs"
+    recs = [json.loads(l) for l in open(logs / "metrics.jsonl")]
+    assert [r["step"] for r in recs] == [0, 1, 2]
+    for r in recs:
+        for key in ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss",
+                    "finetuning/prediction_model_lr"):
+            assert key in r and r[key] == r[key], (key, r)
+        assert r["finetuning/loss"] > 0
+    assert recs[0]["finetuning/prediction_model_lr"] == 0.0 and recs[1]["finetuning/prediction_model_lr"] == 1e-6
+    ups = [r["step"] for r in recs if "finetuning/upper_loss" in r]
+    assert ups == ([1] if upper else []), ups
+    if upper:
+        r = recs[1]
+        assert r["finetuning/upper_prediction_model_lr"] in (0.0, 5e-6) and r["finetuning/upper_diffusion_loss"] == 0.0
+        assert r["finetuning/upper_loss"] > 0 and r["finetuning/upper_loss"] == r["finetuning/upper_distillation_loss"]
+    for ck in ("checkpoint-2", "checkpoint-3"):
+        files = ["unet/diffusion_pytorch_model.safetensors", "unet/config.json", "arch_vector.pt", "optimizer.bin", "scheduler.bin",
+                 "random_states_0.pkl"] + (["optimizer_1.bin", "scheduler_1.bin"] if upper else [])
+        for f in files:
+            assert (logs / ck / f).exists(), (ck, f)
+    # the optimiser really ran with the string-typed epsilon / learning rate
+    osd = torch.load(logs / "checkpoint-3" / "optimizer.bin", weights_only=False)
+    g = osd["param_groups"][0]
+    assert g["eps"] == 1e-8 and g["initial_lr"] == 1e-6 and float(osd["state"][0]["step"]) == 3

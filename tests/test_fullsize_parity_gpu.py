@@ -5,8 +5,9 @@ Round-1 stopped at full-size *losses*; this file closes the remaining BASELINE.j
   configs[0]/[1]/[2]  MAC-budget-0.55 student, B=1, 64x64 latent: main step AND upper (concept-suppression) step -
                       losses + parameter gradients (every tensor; a named set spread over down/mid/up is asserted at the
                       tight tolerance) for the fp32 engine (2e-3 of each tensor's scale) and the bf16 engine (cosine >= 0.98)
-  configs[3]          "82 %-pruned" in its second reading: keep ~ 0.18 of the MACs - main-step losses
-  configs[4]          dense student, 96x96 latents (768^2 images), B=1 - main-step losses (N = 9216 self-attention)
+  configs[3]          "82 %-pruned" in its second reading: keep ~ 0.18 of the MACs - main-step losses AND gradients
+  configs[4]          dense student, 96x96 latents (768^2 images), B=1 (N = 9216 self-attention) - main-step losses AND
+                      gradients, plus one upper step (loss + gradients)
 
 Reference arithmetic: pdm/training/trainer.py:2403-2488 (step), :2904-3001 (upper_step); attention blocks.py:257-277.
 The oracle runs ONCE per (budget, step kind) (module-scoped cache) and both engine dtypes are compared with it.
@@ -185,41 +186,107 @@ def test_full_size_upper_step_loss_and_gradients_match_oracle(dev, dn):
     _check_grads(student, gref, dn)
 
 
-@pytest.mark.parametrize("dn", ["f32", "bf16"])
-def test_keep_018_student_main_step_losses(dev, dn):
-    """BASELINE configs[3] read as "82 % pruned" = 18 % of the MACs kept."""
+def test_full_size_bf16_error_against_both_oracle_precisions(dev):
+    """One full-size data point for the bf16 engine's distance from fp32 (real SD-2.1, MAC budget 0.55, B = 1, 64x64 latent, fixed
+    weights): the student's nine hooked block activations and prediction and the teacher's prediction as relative L2 errors
+    against the fp32 oracle, next to the same quantities of the oracle evaluated under the reference's mixed-precision policy
+    (pdm_ref/step.py mixed="cuda": CUDA autocast, trainer.py:516-527).  The HIP engine must be no further from fp32 than 1.15 x
+    that evaluation on every tensor (tiny topology: 0.82-0.95 x, tests/test_step_parity_gpu.py), and the three main-step loss
+    totals (HIP bf16 / oracle mixed / oracle fp32) are printed and held to the 3e-2 the other bf16 tests use."""
+    from pdm_ref import step as ostep, unet as ounet, weights as oweights
+    from pdm_ref.config import UNetConfig as OCfg
     from pdm.training.bilevel import BilevelStepper
-    (loss, diff, dist_, block), _, av = _oracle("main", 0.18, grads=False)
+    (loss32, _, _, _), _, av = _oracle("main", 0.55)
+    ocfg = OCfg.sd21()
+    dense = _dense()
+    psd, info = oweights.prune_state_dict(dense, ocfg, av)
+    tinfo = oweights.dense_info(ocfg)
+    lat, noise, t, ehs, _ = _inputs()
+    ac = ostep.alphas_cumprod()
+    noisy = ostep.add_noise(ac, lat, noise, t)
+    ref, pol = {}, {}
+    for store, mixed in ((ref, False), (pol, "cuda")):
+        mp = ostep._mixed(mixed)
+        acts = {}
+        with torch.no_grad(), mp.ctx():
+            store["pred"] = ounet.unet_forward(psd, ocfg, info, noisy, t, ehs, acts).float()
+            store["teacher"] = ounet.unet_forward(mp.teacher_sd(dense), ocfg, tinfo, noisy, t, ehs).float()
+        store.update({k_: v.float() for k_, v in acts.items()})
+    with torch.no_grad():
+        loss_mix = float(ostep.main_step_loss((psd, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, mixed="cuda")[0])
+    student, teacher = _models(torch.bfloat16, av)
+    acts = {}
+    for i, h in enumerate(student.down_blocks):
+        h.register_forward_hook(lambda m, inp, out, i=i: acts.__setitem__(f"d{i}", out[0]))
+    student.mid_block.register_forward_hook(lambda m, inp, out: acts.__setitem__("m", out))
+    for i, h in enumerate(student.up_blocks):
+        h.register_forward_hook(lambda m, inp, out, i=i: acts.__setitem__(f"u{i}", out))
+    hip = {"pred": student.eval()(noisy, t, ehs).sample.float().cpu(), "teacher": teacher(noisy, t, ehs).sample.float().cpu()}
+    hip.update({k_: v.float().cpu() for k_, v in acts.items()})
+    student.train()
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    report, bad = {}, []
+    for key in list(ostep.BLOCK_KEYS) + ["pred", "teacher"]:
+        e_hip, e_pol = l2(hip[key], ref[key]), l2(pol[key], ref[key])
+        report[key] = (round(e_hip, 5), round(e_pol, 5))
+        assert e_pol > 1e-3, (key, e_pol)
+        if e_hip > 1.15 * e_pol:
+            bad.append(key)
+    print("full-size relative L2 error vs fp32 (HIP bf16, oracle mixed):", report)
+    assert not bad, (bad, report)
+    st = BilevelStepper(student, teacher)
+    tot = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=False))[0]
+    print(f"full-size main-step loss: HIP bf16 {tot:.6f}  oracle mixed {loss_mix:.6f}  oracle fp32 {loss32:.6f}")
+    assert abs(tot - loss32) <= 3e-2 * abs(loss32) and abs(loss_mix - loss32) <= 3e-2 * abs(loss32), (tot, loss_mix, loss32)
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_keep_018_student_main_step_losses_and_gradients(dev, dn):
+    """BASELINE configs[3] read as "82 % pruned" = 18 % of the MACs kept: the four loss heads and every parameter gradient
+    (NAMED set at the tight tolerance, as at budget 0.55) against the oracle.  trainer.py:2403-2488."""
+    from pdm.training.bilevel import BilevelStepper
+    (loss, diff, dist_, block), gref, av = _oracle("main", 0.18)
     dtype = torch.float32 if dn == "f32" else torch.bfloat16
     student, teacher = _models(dtype, av)
     lat, noise, t, ehs, _ = _inputs()
     st = BilevelStepper(student, teacher)
-    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=(dn == "bf16")))
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda()))
     tol = 1e-3 if dn == "f32" else 3e-2
     for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
         assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
-    if dn == "bf16":
-        gsum = float(student.store.grad.double().abs().sum())
-        assert math.isfinite(gsum) and gsum > 0
+    _check_grads(student, gref, dn)
 
 
 @pytest.mark.parametrize("dn", ["f32", "bf16"])
-def test_dense_student_96x96_latents_main_step_losses(dev, dn):
-    """BASELINE configs[4] shape: dense (unpruned) student, 768^2 images = 96x96 latents, N = 9216 self-attention tokens.
-    (The config's fp8 attention is a precision option; parity is checked on the fp32 engine at 1e-3 and on the bf16 engine.)"""
+def test_dense_student_96x96_latents_main_step_losses_and_gradients(dev, dn):
+    """BASELINE configs[4] shape: dense (unpruned) student, 768^2 images = 96x96 latents, N = 9216 self-attention tokens: loss
+    heads and every parameter gradient against the oracle.  (The config's fp8 attention is a precision option that this build
+    does not have - DESIGN.md 10; parity is checked on the fp32 engine at 1e-3 / 2e-3 and on the bf16 engine.)"""
     from pdm.training.bilevel import BilevelStepper
-    (loss, diff, dist_, block), _, av = _oracle("main", 1.0, hw=96, grads=False)
+    (loss, diff, dist_, block), gref, av = _oracle("main", 1.0, hw=96)
     dtype = torch.float32 if dn == "f32" else torch.bfloat16
     student, teacher = _models(dtype, None, student_sd=_dense(1))
     lat, noise, t, ehs, _ = _inputs(96)
     st = BilevelStepper(student, teacher)
-    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), backward=(dn == "bf16")))
+    tot, d, s, b = st.total(st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda()))
     tol = 1e-3 if dn == "f32" else 3e-2
     for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
         assert abs(got - ref) <= tol * max(abs(ref), 1e-3), (name, got, ref)
-    if dn == "bf16":
-        gsum = float(student.store.grad.double().abs().sum())
-        assert math.isfinite(gsum) and gsum > 0
+    _check_grads(student, gref, dn)
+
+
+def test_dense_student_96x96_latents_upper_step(dev):
+    """The upper (concept-suppression) step at configs[4]'s shape, bf16 engine: teacher on the conditional and the empty
+    prompt (one 2B pass at N = 9216), student forward, negative-guidance target, backward - loss and every gradient against
+    the oracle.  trainer.py:2904-3001."""
+    from pdm.training.bilevel import BilevelStepper
+    (loss, _, dist_, _), gref, av = _oracle("upper", 1.0, hw=96)
+    student, teacher = _models(torch.bfloat16, None, student_sd=_dense(1))
+    lat, noise, t, ehs, empty = _inputs(96)
+    st = BilevelStepper(student, teacher)
+    tot, _, s, _ = st.total(st.upper_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda(), empty.cuda()), upper=True)
+    assert abs(tot - loss) <= 3e-2 * abs(loss) and abs(s - dist_) <= 3e-2 * abs(dist_), (tot, loss, s, dist_)
+    _check_grads(student, gref, "bf16")
 
 
 def _oracle_batch(kind, budget, B):

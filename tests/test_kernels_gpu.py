@@ -1142,6 +1142,67 @@ def test_upsample_conv_as_four_phase_convs(dev, B, H, Ci, Co):
                 assert torch.equal(wpt.view(Ci, 4, 2, 2, Co)[:, p, 1 - dy_, 1 - dx_], got.t())
 
 
+def test_tuner_scratch_has_a_canary_band(dev):
+    """Regression guard of round 3's tuner overrun: the plan cache times candidates into a scratch output it sizes itself; a
+    forward 2x2 phase conv (conv_mode 5..8) stores row m at a pixel of the 2H x 2W image, i.e. anywhere in 4 M rows, and the
+    scratch was sized for M - a silent out-of-bounds write in ordinary runs, a memory fault under the profiler.  With
+    PDMK_DEBUG_SCRATCH=1 every tuning pass gets a fresh scratch of exactly the computed size with a 1 MiB band of 0xA5
+    behind it, checked after the timing launches (pdmk_debug_scratch_violations).  Tuning the four phases - one by one
+    (tune_cfg) and as a group (tune_group) - must leave the band intact; PDMK_DEBUG_SCRATCH=2 sizes the scratch the OLD way
+    for problems whose whole overrun fits the band, and the canary must fire (the check checks)."""
+    import os
+    from pdm import _pdmk as k
+    B, H, Ci, Co = 1, 16, 32, 64
+    W, dt = H, torch.bfloat16
+    torch.manual_seed(5)
+    x = rnd((B * H * W, Ci), dev, dt)
+    w3 = rnd((Co, 9 * Ci), dev, torch.float32, 0.05)
+    bias = rnd((Co,), dev, torch.float32)
+    wp = torch.empty(4, Co, 4 * Ci, device=dev, dtype=dt)
+    wpt = torch.empty(Ci, 16 * Co, device=dev, dtype=dt)
+    k.up2_pack_weights(w3, wp, wpt, Co, Ci)
+    geo = lambda m: (B, H, W, Ci, H, W, m, Ci)
+    Ml, Mh = B * H * W, B * 4 * H * W
+    yr = F.conv2d(F.interpolate(x.float().view(B, H, W, Ci).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"),
+                  w3.view(Co, 3, 3, Ci).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(Mh, Co)
+
+    def run(grouped):
+        y = torch.zeros(Mh, Co, device=dev, dtype=dt)
+        if grouped:
+            with k.Recorder() as r:
+                for p in range(4):
+                    k.gemm(x, wp[p], y, Ml, Co, 4 * Ci, 0, 4 * Ci, Co, a_mode=k.A_CONV, conv=geo(5 + p), bias=bias)
+            k.gemm_group(r.recs)
+        else:
+            for p in range(4):
+                k.gemm(x, wp[p], y, Ml, Co, 4 * Ci, 0, 4 * Ci, Co, a_mode=k.A_CONV, conv=geo(5 + p), bias=bias)
+        torch.cuda.synchronize()
+        close(y.float(), yr, 2e-2, "up2 forward under the scratch canary")
+    saved = {v: os.environ.get(v) for v in ("PDMK_DEBUG_SCRATCH", "PDMK_RING_CFG", "PDMK_WGRAD_CFG")}
+    for v in ("PDMK_RING_CFG", "PDMK_WGRAD_CFG"):
+        os.environ.pop(v, None)
+    try:
+        os.environ["PDMK_DEBUG_SCRATCH"] = "1"
+        k.plan_clear()
+        v0 = k.debug_scratch_violations()
+        run(False)                                     # tune_cfg of every phase
+        assert k.plan_size() >= 4
+        run(True)                                      # tune_group of the four
+        assert k.debug_scratch_violations() == v0, "the tuner wrote behind its scratch"
+        # positive control: size the scratch for M rows again - the canary must notice
+        os.environ["PDMK_DEBUG_SCRATCH"] = "2"
+        k.plan_clear()
+        run(False)
+        assert k.debug_scratch_violations() > v0, "the canary band did not catch a deliberate overrun"
+    finally:
+        for v, val in saved.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
+        k.plan_clear()
+
+
 @pytest.mark.parametrize("cand", [1, 4, 6, 8, 12, 17, 19, -1])
 def test_gemm_fused_geglu_backward_epilogue(dev, force_cfg, cand):
     """PDMK_EPI_GEGLU_BWD: the input gradient of FeedForward's second Linear pushed through GEGLU's backward in the GEMM's

@@ -396,8 +396,9 @@ _CURVE = {}
 def _oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=False):
     """The same 9-iteration bilevel loop on the CPU oracle (autograd + its AdamW restatement); computed once per session
     (it does not depend on the engine dtype under test).  mixed: the oracle in the reference's `--mixed_precision bf16`
-    numerics (bf16-cast teacher, student forward under autocast, fp32 master weights and optimiser)."""
-    key = "mixed" if mixed else "ref"
+    numerics (bf16-cast teacher, student forward under autocast, fp32 master weights and optimiser): True = torch's CPU
+    autocast, "cuda" = CUDA autocast's op policy (fp32 norms, fused-SDPA numerics; pdm_ref/step.py _mixed)."""
+    key = ("mixed-" + str(mixed)) if mixed else "ref"
     if key in _CURVE:
         return _CURVE[key]
     from pdm_ref import step as ostep, weights as oweights
@@ -421,20 +422,80 @@ def _oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=False):
     return ref
 
 
+def _l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_bf16_error_at_fixed_weights_is_below_the_reference_policys(dev):
+    """Where the bf16 engine's distance from the fp32 oracle comes from, measured where it can be measured without chaos: at
+    FIXED weights (no optimiser in the loop), as relative L2 errors over whole tensors.  The comparator is the oracle evaluated
+    the way the reference trains under `--mixed_precision bf16` (CUDA autocast's op policy: bf16 conv / linear / attention
+    products, fp32 norms and softmax, fp32 master weights - pdm_ref/step.py mixed="cuda", trainer.py:516-527).  Every hooked
+    block activation, the prediction, the teacher's prediction and the whole main-step gradient of the HIP engine must be no
+    further from fp32 than 1.15 x that evaluation (measured round 4, tools/bf16_bisect.py: 0.91-0.95 x on every activation,
+    0.82 x on the teacher, 0.885 x on the gradient, every layer kind below 1) - i.e. no op class of the engine keeps less
+    precision than autocast does (epilogues add bias / residual in fp32 before the one rounding, weight gradients stay fp32)."""
+    from pdm_ref import step as ostep, unet as ounet, weights as oweights
+    from pdm.training.bilevel import BilevelStepper
+    ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16, drop_depth=(1, 9))
+    lat, noise, t, ehs, _ = _inputs()
+    ac = ostep.alphas_cumprod()
+    tinfo = oweights.dense_info(ocfg)
+    noisy = ostep.add_noise(ac, lat, noise, t)
+    ref, pol = {}, {}
+    for store, mixed in ((ref, False), (pol, "cuda")):
+        mp = ostep._mixed(mixed)
+        acts = {}
+        with torch.no_grad(), mp.ctx():
+            store["pred"] = ounet.unet_forward(psd, ocfg, info, noisy, t, ehs, acts).float()
+            store["teacher"] = ounet.unet_forward(mp.teacher_sd(dense), ocfg, tinfo, noisy, t, ehs).float()
+        store.update({k_: v.float() for k_, v in acts.items()})
+        P = {k_: v.clone().requires_grad_(True) for k_, v in psd.items()}
+        ostep.main_step_loss((P, info), (dense, tinfo), ocfg, ac, lat, noise, t, ehs, mixed=mixed)[0].float().backward()
+        store["grad"] = torch.cat([P[k_].grad.float().flatten() for k_ in sorted(P)])
+    acts = {}
+    for i, h in enumerate(student.down_blocks):
+        h.register_forward_hook(lambda m, inp, out, i=i: acts.__setitem__(f"d{i}", out[0]))
+    student.mid_block.register_forward_hook(lambda m, inp, out: acts.__setitem__("m", out))
+    for i, h in enumerate(student.up_blocks):
+        h.register_forward_hook(lambda m, inp, out, i=i: acts.__setitem__(f"u{i}", out))
+    hip = {"pred": student.eval()(noisy, t, ehs).sample.float().cpu(), "teacher": teacher(noisy, t, ehs).sample.float().cpu()}
+    hip.update({k_: v.float().cpu() for k_, v in acts.items()})
+    student.train()
+    st = BilevelStepper(student, teacher)
+    st.main_step(lat.cuda(), noise.cuda(), t.cuda(), ehs.cuda())
+    torch.cuda.synchronize()
+    g = student.store.state_dict(arena=student.store.grad)
+    hip["grad"] = torch.cat([g[k_].float().cpu().flatten() for k_ in sorted(g)])
+    report, bad = {}, []
+    for key in list(ostep.BLOCK_KEYS) + ["pred", "teacher", "grad"]:
+        e_hip, e_pol = _l2(hip[key], ref[key]), _l2(pol[key], ref[key])
+        report[key] = (round(e_hip, 5), round(e_pol, 5))
+        assert e_pol > 1e-3, (key, e_pol)                       # the comparator really computes in bf16
+        if e_hip > 1.15 * e_pol:
+            bad.append(key)
+    assert not bad, (bad, report)
+
+
 def test_bf16_curve_error_is_the_dtype_not_the_kernels(dev):
     """north_star asks for loss curves within 1e-3 of the CPU reference; the fp32 engine meets that (test above), the bf16
-    engine cannot - and neither can the reference itself under `--mixed_precision bf16`.  The oracle in the reference's
-    mixed-precision numerics (trainer.py:516-527: bf16-cast teacher, student under autocast, fp32 master weights) gives the
-    distance a CORRECT bf16 implementation keeps from the fp32 curve; the HIP bf16 engine's curve must be no further from
-    the fp32 oracle than that distance x 2, in the RMS over the 12 points and at every single point (against the largest
-    oracle distance on the curve: a single point's oracle distance can be ~0 by luck).  Measured (round 3): oracle-bf16 max
-    1.8e-3 / RMS 0.7e-3, HIP-bf16 max 3.0e-3 / RMS 1.1e-3 relative (ratio 1.6; it moves by +-0.2 with every change of a
-    bf16 rounding order) - both a few times the 1e-3 the fp32 engine meets, neither drifting."""
+    engine cannot - and neither can the reference itself under `--mixed_precision bf16`.  What a bf16 curve's distance from the
+    fp32 curve IS, is measured on the oracle: evaluated under the two op policies torch has for bf16 autocast (CPU autocast;
+    CUDA autocast = the one the reference trains under, pdm_ref/step.py _mixed) the SAME 12-point loop ends max 1.8e-3 / RMS
+    0.7e-3 and max 5.3e-3 / RMS 1.6e-3 away from fp32, and the same policy on two hosts differs point by point by factors of
+    0.3-8 (round 4, tools/bf16_bisect.py).  The distance is chaotic, not systematic: the first Adam steps move every weight by
+    +-lr according to the SIGN of its gradient, so rounding noise on small gradients becomes full-size weight steps, and the three
+    upper-step points (loss ~0.07, a difference of O(1) terms computed without the .float() cast, trainer.py:2994-2999) carry most
+    of it.  The systematic part is pinned by test_bf16_error_at_fixed_weights_is_below_the_reference_policys; here the HIP
+    curve must stay within 1.5 x the envelope of the two oracle evaluations, in the maximum and in the RMS over the 12 points.
+    Round 3 compared with the CPU-autocast evaluation alone, measured 1.6 x on one box and widened the bound to 2.0 x; the same
+    comparison measured 0.70 x in round 4 (HIP max 1.3e-3 / RMS 0.55e-3) - the ratio to ONE evaluation is not a property of the engine."""
     from pdm.training.bilevel import BilevelStepper
     ocfg, dense, psd, info, student, teacher = _setup(torch.bfloat16, drop_depth=(1, 9))
     lr, ulr = 2e-5, 5e-5
     ref = _oracle_curve(ocfg, dense, psd, info, lr, ulr)
-    mix = _oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=True)
+    mixes = [_oracle_curve(ocfg, dense, psd, info, lr, ulr, mixed=m) for m in (True, "cuda")]
     st = BilevelStepper(student, teacher, lr=lr, upper_lr=ulr, bilevel=True)
     hip = []
     for it, (lat, noise, t, ehs, empty) in enumerate(_curve_inputs()):
@@ -446,12 +507,14 @@ def test_bf16_curve_error_is_the_dtype_not_the_kernels(dev):
             st.optimizer_step(upper=name == "upper")
             hip.append(st.total(L, upper=name == "upper")[0])
     rel = lambda a: [abs(x - r) / max(abs(r), 1e-6) for x, r in zip(a, ref)]
-    d_mix, d_hip = rel(mix), rel(hip)
-    assert max(d_mix) > 1e-4, d_mix                           # the mixed oracle really computes in bf16
     rms = lambda d: (sum(x * x for x in d) / len(d)) ** 0.5
-    report = [(round(a, 5), round(b, 5)) for a, b in zip(d_hip, d_mix)]
-    assert max(d_hip) <= 2.0 * max(d_mix), report
-    assert rms(d_hip) <= 2.0 * rms(d_mix), (rms(d_hip), rms(d_mix), report)
+    d_mix, d_hip = [rel(m) for m in mixes], rel(hip)
+    assert all(max(d) > 1e-4 for d in d_mix), d_mix            # the mixed oracles really compute in bf16
+    env_max, env_rms = max(max(d) for d in d_mix), max(rms(d) for d in d_mix)
+    report = [tuple(round(x, 5) for x in p) for p in zip(d_hip, *d_mix)]
+    assert max(d_hip) <= 1.5 * env_max, (max(d_hip), env_max, report)
+    assert rms(d_hip) <= 1.5 * env_rms, (rms(d_hip), env_rms, report)
+    assert max(d_hip) <= 1e-2                                    # and in absolute terms: a few times the fp32 engine's 1e-3
 
 
 def test_deferred_wt_refresh_is_complete_before_backward(dev):

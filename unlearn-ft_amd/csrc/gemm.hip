@@ -616,8 +616,13 @@ int launch_candidate(const pdmk_gemm_args& g, hipStream_t st, int id) {
 
 // rows of C a problem may write: a forward phase of an upsampling conv (conv_mode 5..8) stores row m at a pixel of the
 // 2hi x 2wi image, i.e. anywhere in 4 M rows
+static int debug_scratch();
 long out_rows(const pdmk_gemm_args& g) {
-    return (g.a_mode == PDMK_A_CONV && g.conv_mode >= 5 && g.conv_mode <= 8) ? 4L * g.M : (long)g.M;
+    // PDMK_DEBUG_SCRATCH=2 (the canary's own positive control, tests only): the round-3 bug on purpose - M rows - for problems
+    // whose whole overrun (3 M N fp32) stays inside the canary band
+    const bool phase_fwd = g.a_mode == PDMK_A_CONV && g.conv_mode >= 5 && g.conv_mode <= 8;
+    if (phase_fwd && debug_scratch() == 2 && 3L * g.M * g.N * 4 + 4096 <= (1L << 20)) return (long)g.M;
+    return phase_fwd ? 4L * g.M : (long)g.M;
 }
 
 bool can_tune(hipStream_t st) {
@@ -627,13 +632,54 @@ bool can_tune(hipStream_t st) {
     return cs == hipStreamCaptureStatusNone;
 }
 
+// PDMK_DEBUG_SCRATCH=1 (tests): the scratch is re-allocated for EVERY tuning pass at exactly the size that pass computed, with a
+// band of kCanaryBytes of 0xA5 right behind it; scratch_check() reads the band back after the timing launches.  A candidate
+// that stores outside the rows the tuner sized the scratch for (round 3: the forward phase convs, which store 4 M rows - a silent
+// out-of-bounds write in ordinary runs, a memory fault only under the profiler) turns the band dirty, the tuner returns an error
+// and pdmk_debug_scratch_violations() counts it.
+constexpr size_t kCanaryBytes = 1 << 20;
+size_t g_scratch_req = 0;            // bytes the last pass asked for (the band starts there)
+int g_scratch_violations = 0;
+static int debug_scratch() { static int c = INT32_MIN; return env_int("PDMK_DEBUG_SCRATCH", 0, &c); }
+static_assert(kCanaryBytes == (1 << 20), "out_rows() sizes its deliberate overrun against the band");
+
 bool ensure_scratch(size_t bytes) {
+    if (debug_scratch()) {
+        if (g_scratch) (void)hipFree(g_scratch);
+        g_scratch = nullptr;
+        g_scratch_bytes = 0;
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (hipMalloc(&g_scratch, bytes + kCanaryBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMemset(reinterpret_cast<char*>(g_scratch) + bytes, 0xA5, kCanaryBytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+        (void)hipDeviceSynchronize();
+        g_scratch_bytes = bytes + kCanaryBytes;
+        g_scratch_req = bytes;
+        return true;
+    }
     if (bytes <= g_scratch_bytes) return true;
     if (g_scratch) (void)hipFree(g_scratch);
     g_scratch = nullptr;
     g_scratch_bytes = 0;
     if (hipMalloc(&g_scratch, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
     g_scratch_bytes = bytes;
+    return true;
+}
+
+// true when the band behind the scratch is intact (or the debug mode is off)
+bool scratch_check() {
+    if (!debug_scratch() || !g_scratch) return true;
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned char> host(kCanaryBytes);
+    if (hipMemcpy(host.data(), reinterpret_cast<char*>(g_scratch) + g_scratch_req, kCanaryBytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    for (size_t i = 0; i < kCanaryBytes; ++i)
+        if (host[i] != 0xA5) {
+            ++g_scratch_violations;
+            fprintf(stderr, "[pdmk] tuner scratch overrun: byte %zu behind a %zu-byte scratch was overwritten\n", i, g_scratch_req);
+            return false;
+        }
     return true;
 }
 
@@ -704,6 +750,7 @@ int tune_cfg(const pdmk_gemm_args& g, hipStream_t st, int sk, float* t_out) {
     if (getenv("PDMK_TUNE_LOG"))
         fprintf(stderr, "[pdmk tune] M=%d N=%d K=%d amode=%d cmode=%d sk=%d -> cand %d (%.1f us)\n", g.M, g.N, g.K, g.a_mode,
                 g.conv_mode, sk, best, bt);
+    if (!scratch_check()) return -1;
     *t_out = bt;
     return best;
 }
@@ -961,6 +1008,10 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
         for (int i = 0; i < n; ++i) fprintf(stderr, " (%d,%d,%d|a%d sk%d id%d)", a[i].M, a[i].N, a[i].K, a[i].a_mode, a[i].splitk, ids[i]);
         fprintf(stderr, " separate %.1f us -> %s %d (%.1f us)\n", t_sep, best > 0 ? "grouped cand" : "separate", best, best > 0 ? bt : t_sep);
     }
+    {
+        std::lock_guard<std::mutex> lk(g_plan_mu);
+        if (!scratch_check()) return -1;
+    }
     return best;
 }
 
@@ -1145,4 +1196,11 @@ extern "C" int pdmk_plan_clear(void) {
     return 0;
 }
 
-extern "C" int pdmk_version(void) { return 120; }
+// tuner-scratch overruns seen since the process started (PDMK_DEBUG_SCRATCH=1: a canary band behind the scratch, checked after
+// every tuning pass); always 0 when the debug mode is off
+extern "C" int pdmk_debug_scratch_violations(void) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    return g_scratch_violations;
+}
+
+extern "C" int pdmk_version(void) { return 121; }

@@ -105,6 +105,7 @@ _SIGS = {
     "pdmk_plan_import": ([C.c_char_p], i32),
     "pdmk_plan_size": ([], i32),
     "pdmk_plan_clear": ([], i32),
+    "pdmk_debug_scratch_violations": ([], i32),
     "pdmk_comm_unique_id": ([vp], i32),
     "pdmk_comm_create": ([vp, i32, i32, C.POINTER(vp)], i32),
     "pdmk_comm_allreduce_sum_f32": ([vp, vp, i64, vp], i32),
@@ -323,6 +324,11 @@ def plan_clear():
     _chk(_lib.pdmk_plan_clear(), "pdmk_plan_clear")
 
 
+def debug_scratch_violations():
+    """Tuning passes that overran their scratch since the process started (PDMK_DEBUG_SCRATCH=1; else 0)."""
+    return int(_lib.pdmk_debug_scratch_violations())
+
+
 class Comm:
     """pdmk_comm_t: RCCL communicator behind the C ABI (one per rank; `uid` = the 128 bytes rank 0 got from unique_id())."""
 
@@ -337,6 +343,13 @@ class Comm:
         buf = C.create_string_buffer(128)
         _chk(_lib.pdmk_comm_unique_id(buf), "pdmk_comm_unique_id")
         return bytes(buf.raw)
+
+    def world_size(self):
+        """What the HANDLE says (pdmk_comm_world / pdmk_comm_rank), not what the constructor was told."""
+        return int(_lib.pdmk_comm_world(self._h))
+
+    def rank_id(self):
+        return int(_lib.pdmk_comm_rank(self._h))
 
     def all_reduce_sum_(self, t):
         """In-place sum over the ranks of a contiguous fp32 tensor, asynchronous on torch's current HIP stream."""

@@ -143,10 +143,15 @@ class GradReducer:
     reduced in `bucket_mb` slices issued on the dedicated comm stream as soon as the backward pass has produced them (the
     arena is laid out in forward order, so the tail is final first); the division by world size is folded into AdamW.
 
-    mode "allreduce" (default): one all-reduce per bucket.  mode "rs_ag" (PDMK_DP_MODE=rs_ag): every bucket
-    as reduce-scatter + all-gather of world equal shares - over RCCL each rank receives its share directly from its xGMI
-    peers; a bucket's last (n mod world) elements ride in a small all-reduce.  Both modes give the same sums.
-    transport: torch.distributed's process group (default) or the library's own communicator (PDMK_COMM=native)."""
+    mode "allreduce" (default): one all-reduce per bucket.  mode "rs_ag" (PDMK_DP_MODE=rs_ag; EXPERIMENTAL -
+    its RCCL branch has never run on more than one GPU): every bucket as reduce-scatter + all-gather of world
+    equal shares - over RCCL each rank receives its share directly from its xGMI peers; a bucket's last (n mod world) elements
+    ride in a small all-reduce.  Both modes give the same sums.
+    transport: torch.distributed's process group (default) or the library's own communicator (PDMK_COMM=native).
+    The torch.distributed branch of rs_ag receives this rank's share in a SCRATCH buffer (`_share`) and gathers out of it:
+    whether `reduce_scatter_tensor(out, in)` / `all_gather_into_tensor(out, in)` accept an output that aliases the input
+    depends on the backend (NCCL / RCCL document exactly the in-place placement `in + rank * count`; others do not), and
+    1 / world of a bucket is cheap.  The native communicator uses RCCL's documented in-place form (comm.hip)."""
 
     def __init__(self, store, bucket_mb=64, mode=None):
         self.store = store
@@ -168,6 +173,11 @@ class GradReducer:
             box = [k.Comm.unique_id() if dist.get_rank() == 0 else None]
             dist.broadcast_object_list(box, src=0)
             self.comm = k.Comm(box[0], dist.get_rank(), self.world)
+            # the handle and torch.distributed must describe the same job: share r of a bucket belongs to rank r of BOTH
+            if (self.comm.world_size(), self.comm.rank_id()) != (self.world, self.rank):
+                raise RuntimeError(f"pdmk_comm_t is rank {self.comm.rank_id()} of {self.comm.world_size()}, "
+                                   f"torch.distributed says rank {self.rank} of {self.world}")
+        self._share = None                 # rs_ag over torch.distributed: this rank's share of a bucket (scratch)
 
     def begin(self):
         self.next_hi = self.store.total
@@ -199,7 +209,6 @@ class GradReducer:
         if n:
             body = t[:n]
             per = n // W
-            mine = body[self.rank * per:(self.rank + 1) * per]
             self.n_collectives += 2
             if self.comm is not None:
                 self.comm.reduce_scatter_sum_(body)
@@ -210,8 +219,11 @@ class GradReducer:
                 for r in range(W):
                     dist.broadcast(body[r * per:(r + 1) * per], src=r)
             else:
-                dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM)
-                dist.all_gather_into_tensor(body, mine)
+                if self._share is None or self._share.numel() < per or self._share.device != t.device:
+                    self._share = torch.empty(max(per, (self.bucket + W - 1) // W), dtype=t.dtype, device=t.device)
+                share = self._share[:per]              # never aliases the bucket (see the class docstring)
+                dist.reduce_scatter_tensor(share, body, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(body, share)
         if n < t.numel():
             self._all_reduce(t[n:])
 
