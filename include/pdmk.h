@@ -155,7 +155,7 @@ int pdmk_groupnorm_apply_colstat(const void* x, void* y, const float* gamma, con
 int pdmk_up2_pack_weights(const float* w3, void* wp, void* wpt, int Co, int Ci, int dtype, pdmk_stream stream);
 int pdmk_up2_combine_wgrad(const float* dwp, float* dw3, int Co, int Ci, pdmk_stream stream);
 #define PDMK_COLSTAT_SCALE 1073741824.0 /* 2^30: fixed-point unit of the colstat accumulators (two 64-bit limbs per number) */
-#define PDMK_GEMM_GROUP_MAX 4
+#define PDMK_GEMM_GROUP_MAX 8
 int pdmk_gemm_group(const pdmk_gemm_args* args, int n, pdmk_stream stream, int32_t* grouped_out);
 /* Planner for a forward / dgrad GEMM described by `args` (splitk ignored): *splitk_out = the split-K factor the caller
  * should use (1 = plain call; > 1 = accumulate fp32 partials into a zeroed [M,N] workspace with out_f32 + splitk, then
@@ -253,9 +253,13 @@ int64_t pdmk_groupnorm_bwd_part_workspace_bytes(int G, int gs);
 /* LayerNorm over the last dim (eps 1e-5; diffusers BasicTransformerBlock.norm1/2/3). stats [M,2]. */
 int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* stats, int M, int C,
                        int ldx, int ldy, float eps, int dtype, pdmk_stream stream);
+/* add (optional, row stride ldadd; round 4): a second finished gradient of x folded into the same store, as in
+ * pdmk_groupnorm_bwd - the residual stream's gradient (BasicTransformerBlock's `attn_output + hidden_states`,
+ * blocks.py:705-867 backward) is handed over without an in-place update of a buffer a deferred weight gradient still reads. */
 int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
                        float* dgamma, float* dbeta, float* part_ws, int64_t part_ws_elems /* >= (M/16 + 1) * 2 * C */,
-                       int M, int C, int ldx, int lddy, int lddx, int accumulate_dx, int dtype, pdmk_stream stream);
+                       int M, int C, int ldx, int lddy, int lddx, int accumulate_dx, const void* add, int ldadd, int dtype,
+                       pdmk_stream stream);
 int64_t pdmk_layernorm_bwd_part_workspace_bytes(int M, int C);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -174,6 +174,25 @@ def test_reference_yaml_numbers_without_a_decimal_point_arrive_as_strings(tmp_pa
     assert cfg.training.mixed_precision is None and cfg.model.prediction_model.resolution == 128
 
 
+def test_block_type_strings_of_the_shipped_recipes_are_accepted():
+    """CPU: `unet_down_blocks` / `unet_up_blocks` carry the FACTORY names of get_down_block / get_up_block
+    (unet_2d_conditional.py:119, 217, 397, 477: "...HalfGated" -> the *WidthHalfDepthGated containers; "UNetRes" prefix stripped,
+    :90, :382); round 3 accepted only the container class names, so no shipped recipe could drive the trainer."""
+    from pdm.models.unet import unet_2d_conditional as U
+    from pdm.models.unet.spec import UNetConfig
+    cfg = UNetConfig.sd21()
+    down = ["CrossAttnDownBlock2DHalfGated"] * 3 + ["DownBlock2DHalfGated"]
+    up = ["UpBlock2DHalfGated"] + ["CrossAttnUpBlock2DHalfGated"] * 3
+    U._check_block_types(down, U._GATED_DOWN, cfg.attn_stages_down, "down")
+    U._check_block_types(up, U._GATED_UP, cfg.attn_stages_up, "up")
+    U._check_block_types(["UNetRes" + n for n in down], U._GATED_DOWN, cfg.attn_stages_down, "down")
+    U._check_block_types(["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"], U._GATED_DOWN, cfg.attn_stages_down, "down")     # the teacher's
+    with pytest.raises(ValueError):
+        U._check_block_types(["CrossAttnDownBlock2DGated"] * 3 + ["DownBlock2DGated"], U._GATED_DOWN, cfg.attn_stages_down, "down")
+    with pytest.raises(ValueError):      # a different topology must not be built silently
+        U._check_block_types(list(reversed(down)), U._GATED_DOWN, cfg.attn_stages_down, "down")
+
+
 def _main_of(script):
     spec = importlib.util.spec_from_file_location("entry_" + script, os.path.join(SCRIPTS, script + ".py"))
     mod = importlib.util.module_from_spec(spec)

@@ -896,6 +896,71 @@ def test_groupnorm_bwd_extra_addend(dev, dn):
         close(dg2, dg, 1e-5, "dgamma unchanged")
 
 
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+@pytest.mark.parametrize("C,M", [(64, 37), (320, 300), (1280, 64)])
+def test_layernorm_bwd_extra_addend(dev, dn, C, M):
+    """pdmk_layernorm_bwd(add=...): dx (+)= LN-backward + add in one store - the residual stream's finished gradient
+    (BasicTransformerBlock `attn_output + hidden_states`, blocks.py:705-867 backward) - with and without accumulation into dx,
+    strided addend; the affine gradients do not change."""
+    from pdm import _pdmk as k
+    torch.manual_seed(25)
+    dt = DT[dn]
+    x = rnd((M, C), dev, dt) + 0.3
+    gamma, beta = torch.randn(C, device=dev) * 0.3 + 1, torch.randn(C, device=dev) * 0.3
+    y = torch.zeros_like(x)
+    stats = torch.zeros(M, 2, device=dev)
+    k.layernorm_fwd(x, y, gamma, beta, stats, M, C, C, C, 1e-5)
+    dy = rnd((M, C), dev, dt)
+    addbuf = rnd((M, C + 16), dev, dt)
+    add = addbuf[:, 8:8 + C]
+    ref = torch.zeros_like(x)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    k.layernorm_bwd(x, dy, ref, gamma, stats, dg, db, M, C, C, C, C, False)
+    for acc in (False, True):
+        dx = rnd((M, C), dev, dt)
+        base = dx.float().clone() if acc else 0.0
+        dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        k.layernorm_bwd(x, dy, dx, gamma, stats, dg2, db2, M, C, C, C, C, acc, add=add)
+        close(dx, ref.float() + add.float() + base, TOL[dn] * 2, f"ln bwd + addend (acc={acc})")
+        close(dg2, dg, 1e-5, "dgamma unchanged")
+        close(db2, db, 1e-5, "dbeta unchanged")
+
+
+def test_wgrad_group_of_a_transformer_block_matches_separate_launches(dev):
+    """pdm._pdmk.wgrad_group: the eight Linear weight gradients of one transformer block (one reduction length, outputs from
+    [208, 208] to [1664, 208], two of them with a bias gradient) as grouped launches with ONE split factor against the same
+    gradients computed one by one (k.wgrad, each with its own plan) and against fp32 torch; a second group of another reduction
+    length in the same call.  Same arithmetic up to the fp32 summation order."""
+    from pdm import _pdmk as k
+    torch.manual_seed(31)
+    dt = torch.bfloat16
+    P1, P2 = 4096, 1024
+    shapes = [(624, 208, P1, True), (208, 208, P1, True), (208, 208, P1, False), (208, 208, P1, True), (1664, 208, P1, True),
+              (208, 832, P1, True), (208, 208, P1, True), (208, 208, P1, False), (320, 320, P2, True), (320, 640, P2, False),
+              (224, 96, P2, True)]
+    items, refs, seps, q = [], [], [], k.SlabQueue()
+    for No, Ki, P, has_bias in shapes:
+        dy, x = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
+        dW = torch.randn(No, Ki, device=dev) * 0.1                 # gradients ACCUMULATE into the arena
+        db = torch.randn(No, device=dev) * 0.1 if has_bias else None
+        refs.append((dW + dy.float().t() @ x.float(), None if db is None else db + dy.float().sum(0)))
+        dW2, db2 = dW.clone(), None if db is None else db.clone()
+        k.wgrad(dy, x, dW2, No, Ki, P, No, Ki, colsum_out=db2)
+        seps.append((dW2, db2))
+        items.append((dy, x, dW, No, Ki, P, No, Ki, db, No * Ki * P))
+    k.STATS.update(launches=0, grouped=0)
+    k.wgrad_group(items, q)
+    q.flush()
+    torch.cuda.synchronize()
+    assert k.STATS["launches"] >= 2                                 # one grouped call per reduction length
+    for (dy, x, dW, No, Ki, P, *_rest), (rW, rb), (sW, sb), it in zip(items, refs, seps, items):
+        close(dW, rW, 2e-3, f"grouped wgrad {No}x{Ki} P={P}")
+        close(dW, sW, 1e-4, f"grouped vs separate wgrad {No}x{Ki} P={P}")
+        if rb is not None:
+            close(it[8], rb, 2e-3, "grouped bias gradient")
+            close(it[8], sb, 1e-4, "grouped vs separate bias gradient")
+
+
 def test_comm_handle_single_rank_allreduce(dev):
     """pdmk_comm_t (the C ABI's communicator handle): id -> create -> in-place fp32 all-reduce(sum) on a side stream ->
     destroy, on a world of one rank (all this one-GPU box can host: RCCL refuses two ranks on one device; the N-rank

@@ -989,11 +989,15 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
     float bt = t_sep * 0.98f;                           // a group must win by > 2 %
     // candidates: the members' own plans, the static heuristic's pick for the first member and - for convs - the halo shapes
     // (a shape that loses as a single 256-workgroup launch can win once four problems fill the grid)
-    int cands[PDMK_GEMM_GROUP_MAX + 5], nc = 0;
+    int cands[PDMK_GEMM_GROUP_MAX + 12], nc = 0;
     for (int i = 0; i < n; ++i) cands[nc++] = ids[i];
     cands[nc++] = heuristic_cfg(a[0]);
     if (a[0].a_mode == PDMK_A_CONV)
         for (int h = 0; h < 4; ++h) cands[nc++] = 1 + 12 + h;            // 1 + kNumBase + h (gemm_ring.hip)
+    // Linear weight gradients (the block groups of pdm._pdmk.wgrad_group): every ring tile shape - a member's own plan was timed
+    // with that member alone on the chip, where small tiles win by workgroup count; a full group has the workgroups
+    if (a[0].a_mode == PDMK_A_COLK && a[0].b_mode == PDMK_B_COLK)
+        for (int w = 0; w < 5; ++w) cands[nc++] = 1 + w;                 // kWCfgs (gemm_ring.hip)
     for (int i = 0; i < nc; ++i) {
         bool seen = cands[i] <= 0;
         for (int j = 0; j < i; ++j) seen = seen || cands[j] == cands[i];

@@ -781,7 +781,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
                                                     T* __restrict__ dx, const float* __restrict__ gamma,
                                                     const float* __restrict__ stats, float* __restrict__ part,
                                                     int M, int C, int ldx, int lddy,
-                                                    int lddx, int accumulate, int rows_per_wave) {
+                                                    int lddx, int accumulate, int rows_per_wave,
+                                                    const T* __restrict__ add, int ldadd) {
+    // add (optional): a second finished gradient of the same tensor (the residual branch's, blocks.py:705-867) added in this
+    // store - dx = (accumulate ? dx : 0) + add + this layer's input gradient - so that the fan-in needs neither a pass of its
+    // own nor an in-place update of a buffer another kernel still reads (a deferred weight gradient's dY)
     constexpr int V = Vec<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunks = C / V;
@@ -864,11 +868,13 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ x, con
                 for (int sl = 0; sl < SLOTS; ++sl) {
                     const int c = lane + 64 * sl;
                     if (c < nchunks) {
-                        float o[V];
+                        float o[V], a2[V];
                         if (accumulate) Vec<T>::load(dx + (long)m * lddx + c * V, o);
+                        if (add) Vec<T>::load(add + (long)m * ldadd + c * V, a2);
 #pragma unroll
                         for (int e = 0; e < V; ++e) {
-                            const float v = rstd[q] * (d[q][sl][e] * gm[sl][e] - s1 - xh[q][sl][e] * s2);
+                            float v = rstd[q] * (d[q][sl][e] * gm[sl][e] - s1 - xh[q][sl][e] * s2);
+                            if (add) v += a2[e];
                             o[e] = accumulate ? o[e] + v : v;
                         }
                         Vec<T>::store(dx + (long)m * lddx + c * V, o);
@@ -930,16 +936,16 @@ static int ln_bwd_rpw(int M) {
 template <typename T>
 int ln_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats, float* dgamma,
            float* dbeta, float* part, long part_elems, int M, int C, int ldx, int lddy, int lddx, int acc,
-           hipStream_t st) {
+           const void* add, int ldadd, hipStream_t st) {
     constexpr int V = Vec<T>::N;
-    if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64) return -1;
+    if (C % V || ldx % V || lddy % V || lddx % V || C / V > LN_MAXS * 64 || (add && (ldadd % V))) return -1;
     const int rpw = ln_bwd_rpw(M);
     const int rows_per_blk = 4 * rpw;
     const dim3 grid((M + rows_per_blk - 1) / rows_per_blk);
     if (!part || (long)grid.x * 2 * C > part_elems) return -1;
     const int slots = (C / V + 63) / 64;
 #define PDMK_LNB(S, RR) hipLaunchKernelGGL((ln_bwd_kernel<T, S, RR>), grid, dim3(NT), 0, st, (const T*)x, (const T*)dy, \
-                                           (T*)dx, gamma, stats, part, M, C, ldx, lddy, lddx, acc, rpw)
+                                           (T*)dx, gamma, stats, part, M, C, ldx, lddy, lddx, acc, rpw, (const T*)add, ldadd)
     if (slots <= 1) PDMK_LNB(1, 4);
     else if (slots == 2) PDMK_LNB(2, 2);
     else if (slots == 3) PDMK_LNB(3, 2);
@@ -1040,8 +1046,9 @@ extern "C" int pdmk_layernorm_fwd(const void* x, void* y, const float* gamma, co
 }
 extern "C" int pdmk_layernorm_bwd(const void* x, const void* dy, void* dx, const float* gamma, const float* stats,
                                   float* dgamma, float* dbeta, float* part_ws, int64_t part_ws_elems, int M, int C,
-                                  int ldx, int lddy, int lddx, int accumulate_dx, int dtype, pdmk_stream stream) {
+                                  int ldx, int lddy, int lddx, int accumulate_dx, const void* add, int ldadd, int dtype,
+                                  pdmk_stream stream) {
     if (!x || !dy || !dx || !gamma || !stats || (!dgamma != !dbeta) || M <= 0) return -1;
     PDMK_DISPATCH(dtype, ln_bwd, x, dy, dx, gamma, stats, dgamma, dbeta, part_ws, (long)part_ws_elems, M, C, ldx, lddy,
-                  lddx, accumulate_dx, (hipStream_t)stream);
+                  lddx, accumulate_dx, add, ldadd, (hipStream_t)stream);
 }

@@ -65,7 +65,7 @@ _SIGS = {
     "pdmk_reduce_partials_group": ([vp, i32, vp], i32),
     "pdmk_splitk_finish_group": ([vp, i32, vp], i32),
     "pdmk_layernorm_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
-    "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_layernorm_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], i32),
     "pdmk_attn_fwd": ([vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, i32, vp], i32),
     "pdmk_attn_bwd": ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32,
                        i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, vp, i64, i32, vp], i32),
@@ -157,7 +157,7 @@ PROFILE = None   # bench.py sets this to a list: every gemm launch is then brack
 # happens at record time; records keep their operand tensors alive until they have run.
 RECORD = None
 TAG = ""         # set by the engine before every layer op: records of the same layer op of two models share a tag
-GROUP_MAX = 4
+GROUP_MAX = 8
 STATS = {"launches": 0, "grouped": 0}      # launches issued through records since the last reset (tests / bench bookkeeping)
 
 
@@ -548,6 +548,44 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
          accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
 
 
+def wgrad_group(items, queue, target_wgs=512):
+    """The Linear weight gradients of one transformer block (blocks.py:705-867 backward: to_q/k/v, to_out, ff.net.0.proj,
+    ff.net.2, proj_in, proj_out reached from accelerator.backward, trainer.py:2782) as grouped launches (pdmk_gemm_group): every
+    item reduces over the SAME K pixel rows into a small [M, N] output, so one problem alone fills the 256 CUs only by cutting its
+    reduction into 16-32 splits (16 K-steps each behind a cold prologue, 16-32 slabs to add); together the problems have the tiles,
+    so they share ONE split factor chosen for the group (>= 32 K-steps per split) and one launch.
+    items: (dy, x, dW, M, N, K, lda, ldb, colsum_out, macs) with dW fp32 [M, N] contiguous; queue: the SlabQueue that adds the
+    slabs of split problems later.  Problems the grouped kernels do not take go out one by one (same results either way)."""
+    items = list(items)
+    while items:
+        K = items[0][5]
+        same = [it for it in items if it[5] == K][:GROUP_MAX]
+        items = [it for it in items if not any(it is s_ for s_ in same)]
+        tiles = sum(((it[3] + 127) // 128) * ((it[4] + 127) // 128) for it in same)
+        nk = max(1, K // 64)
+        sk = max(1, min(target_wgs // max(tiles, 1), nk // 32, 64))
+        if len(same) == 1 or queue is None:
+            for dy, x, dW, M, N, K_, lda, ldb, cs, macs in same:
+                wgrad(dy, x, dW, M, N, K_, lda, ldb, colsum_out=cs, macs=macs, queue=queue)
+            continue
+        with Recorder() as r:
+            slabs = []
+            for dy, x, dW, M, N, K_, lda, ldb, cs, macs in same:
+                if sk > 1 and (M * N) % 4 == 0 and dW.is_contiguous():
+                    ws = torch.empty(sk * M * N, device=dy.device, dtype=torch.float32)
+                    gemm(dy, x, ws, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=B_COLK, out_f32=True, splitk=sk, accumulate=2,
+                         dtype=dt(x), macs=macs, colsum_out=cs)
+                    slabs.append((ws, dW, M * N, sk))
+                else:
+                    gemm(dy, x, dW, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=B_COLK, out_f32=True, splitk=1, accumulate=True,
+                         dtype=dt(x), macs=macs, colsum_out=cs)
+        gemm_group(r.recs)
+        for ws, dW, n, nslab in slabs:
+            if queue.full():
+                queue.flush()
+            queue.add(ws, dW, n, nslab)
+
+
 @_recordable("groupnorm_apply_colstat")
 def groupnorm_apply_colstat(x, y, gamma, beta, stats, colstat, col0, B, HW, Cc, ldx, ldy, G, gs, eps, silu):
     """GroupNorm(+SiLU) forward with the statistics taken from a producing GEMM's epilogue sums (colstat [B, 4, cs_ld] int64 limbs)."""
@@ -631,7 +669,8 @@ def layernorm_fwd(x, y, gamma, beta, stats, M, Cc, ldx, ldy, eps):
          "pdmk_layernorm_fwd")
 
 
-def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc, queue=None):
+def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx, acc, queue=None, add=None):
+    """add: a second finished gradient of x ([M, Cc], any row stride) folded into the store of dx."""
     if queue is not None:
         nblk, n = _dims(_lib.pdmk_layernorm_bwd_partial_dims, M, Cc)
         pw = queue.slab(x.device, nblk, n, dgamma, dbeta)
@@ -639,7 +678,8 @@ def layernorm_bwd(x, dy, dx, gamma, stats, dgamma, dbeta, M, Cc, ldx, lddy, lddx
     else:
         pw = part_ws(x.device, _ws_bytes(_lib.pdmk_layernorm_bwd_part_workspace_bytes(M, Cc)) // 4)
     _chk(_lib.pdmk_layernorm_bwd(_p(x), _p(dy), _p(dx), _p(gamma), _p(stats), _p(dgamma), _p(dbeta), _p(pw),
-                                 pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), dt(x), _st()), "pdmk_layernorm_bwd")
+                                 pw.numel(), M, Cc, ldx, lddy, lddx, int(acc), _p(add), 0 if add is None else add.stride(0),
+                                 dt(x), _st()), "pdmk_layernorm_bwd")
 
 
 @_recordable("attn_fwd")

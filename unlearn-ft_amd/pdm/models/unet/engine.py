@@ -22,10 +22,11 @@ class Act:
     pend: a second finished gradient buffer waiting to be added to `g` (the residual branch's, blocks.py:379).  Reading
     `.g` adds it first (one strided accumulate pass); the GroupNorm backward of the same tensor - the usual next writer -
     takes it as an extra addend of its own store instead, so the fan-in normally costs no pass at all."""
-    __slots__ = ("t", "_g", "rg", "pend", "src", "cs")
+    __slots__ = ("t", "_g", "rg", "pend", "src", "cs", "parked")
 
     def __init__(self, t, rg=True):
         self.t, self._g, self.rg, self.pend = t, None, rg, None
+        self.parked = False  # pend is a buffer a deferred (grouped) weight gradient still reads: it must not be updated in place
         self.cs = None       # (accumulator [B, 2, ld], first column, columns covered): per-(image, column) sums of this tensor from
                              # its producers' epilogues (pdmk_gemm_args.colstat) - the GroupNorm that reads it skips its statistics pass
         self.src = None      # a GEGLU output: (pre-activation tensor, the projection's Act) - its consumer's input gradient can be
@@ -34,6 +35,9 @@ class Act:
     def flush(self):
         if self.pend is not None:
             p_, self.pend = self.pend, None
+            if self._g is None:          # parked first gradient and nothing else arrived: it IS the gradient (read-only from here on)
+                self._g = p_
+                return
             k.copy2d(p_, self._g, p_.shape[0], p_.shape[1], p_.stride(0), self._g.stride(0), accumulate=True)
 
     @property
@@ -93,6 +97,10 @@ class UNetEngine:
         # GroupNorm statistics from the producing GEMM's epilogue (PDMK_GN_EPI=0: a statistics pass per GroupNorm).  The
         # per-(image, column) accumulators of one forward pass live in ONE arena zeroed by one launch at its start
         self.gn_epi = os.environ.get("PDMK_GN_EPI", "1") != "0" and dtype == torch.bfloat16
+        # Linear weight gradients of a transformer block: collected during the block's backward and issued as grouped launches at
+        # its start marker (k.wgrad_group; PDMK_WGRAD_GROUP=0: one launch per weight, as they are produced)
+        self.group_wgrad = os.environ.get("PDMK_WGRAD_GROUP", "1") != "0" and dtype == torch.bfloat16 and self.slabs is not None
+        self._wg_items = None
         self._cs_arena, self._cs_off, self._cs_need, self._cs_old = None, 0, 0, []
         self._cs_views, self._cs_cats = {}, {}
 
@@ -106,18 +114,30 @@ class UNetEngine:
         add = None
         if absorb:
             add, act.pend = act.pend, None
+        elif act._g is None and act.pend is not None:
+            # a parked gradient met a writer that cannot take an addend: it gets a private copy to accumulate into (the parked
+            # buffer itself stays as the deferred weight gradient reads it)
+            p_, act.pend = act.pend, None
+            act.g = self._empty(rows, cols, act.t.dtype)
+            k.copy2d(p_, act._g, rows, cols, _ld(p_), _ld(act._g))
+            return act._g, True
         if act._g is None:
             act.g = self._empty(rows, cols, act.t.dtype)
             return (act._g, False, add) if absorb else (act._g, False)
         act.flush()
         return (act._g, True, add) if absorb else (act._g, True)
 
-    def _give(self, act, dy):
+    def _give(self, act, dy, park=False):
         """act.g += dy where dy is a finished gradient buffer: aliased when act has no gradient yet, else parked as the
-        pending addend (folded in by the next GroupNorm backward of act, or on the next read of act.g)."""
+        pending addend (folded in by the next GroupNorm / LayerNorm backward of act, or on the next read of act.g).
+        park: dy is also the operand of a DEFERRED weight gradient (_wg_items): never aliased as a buffer later kernels accumulate
+        into - it waits as the pending addend even when it is the first gradient to arrive."""
         if not act.rg:
             return
-        if act._g is None:
+        if act._g is None and park and act.pend is None:
+            act.pend = dy
+            act.parked = True
+        elif act._g is None:
             act.g = dy
         elif self.defer_fanin and dy.dtype == act._g.dtype:
             act.flush()
@@ -154,6 +174,9 @@ class UNetEngine:
         """Deferred norm-affine gradient reductions (PartialQueue): after this every gradient the tape has produced so far is
         final in the arena.  Called by whoever consumes gradients mid-backward (bucketed all-reduce, streamed AdamW, graph
         cut) and at the end of backward()."""
+        if self._wg_items:          # (a consumer in the middle of a transformer block: what was collected so far goes out now)
+            items, self._wg_items = self._wg_items, []
+            k.wgrad_group(items, self.slabs)
         if self.partials is not None:
             self.partials.flush()
         if self.slabs is not None:
@@ -240,11 +263,17 @@ class UNetEngine:
                     k.cast_permute(dy, dyc, M * Np, 1, 1, 0)
                     dy = dyc
                 xt = x.t
-                # wgrad first (side stream if enabled), dgrad second: the two GEMMs of one layer can run side by side
-                self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), macs=lmacs,
-                                            colsum_out=P.g(bias) if bias else None,   # bias gradient fused in
-                                            queue=None if self.wgrad_async else self.slabs),
-                            dy, xt)
+                collect = self._wg_items is not None and not self.wgrad_async
+                if collect:      # inside a transformer block: the weight gradient joins the block's grouped launch (dy and xt
+                    # stay referenced - and unmodified, see _give(park=True) - until _wg_flush)
+                    self._wg_items.append((dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt),
+                                           P.g(bias) if bias else None, lmacs))
+                else:
+                    # wgrad first (side stream if enabled), dgrad second: the two GEMMs of one layer can run side by side
+                    self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Np, Kp, M, _ld(dy), _ld(xt), macs=lmacs,
+                                                colsum_out=P.g(bias) if bias else None,   # bias gradient fused in
+                                                queue=None if self.wgrad_async else self.slabs),
+                                dy, xt)
                 fused_g = False
                 if (x.rg and x.src is not None and x._g is None and self.fuse_geglu_bwd and self.dtype == torch.bfloat16 and
                         k.splitk_plan(dy, P.wtv(key + ".weight"), M, Kp, Np, _ld(dy), Np) == 1):
@@ -259,7 +288,7 @@ class UNetEngine:
                                 macs=lmacs)
                 if residual is not None:
                     self._wgrad_fence()
-                    self._give(residual, out.g)
+                    self._give(residual, out.g, park=collect)
             self.tape.append(bwd)
         if geglu:
             act = Act(gl)
@@ -500,9 +529,9 @@ class UNetEngine:
         out = Act(y)
         if self.train:
             def bwd():
-                dx, acc = self._grad_into(x, M, C)
+                dx, acc, add = self._grad_into(x, M, C, absorb=True)     # add: the residual branch's finished gradient
                 k.layernorm_bwd(x.t, out.g, dx, gw, stats, P.g(key + ".weight"), P.g(key + ".bias"), M, C, _ld(x.t),
-                                _ld(out.g), _ld(dx), acc, queue=self.partials)
+                                _ld(out.g), _ld(dx), acc, queue=self.partials, add=add)
             self.tape.append(bwd)
         return out
 
@@ -648,6 +677,8 @@ class UNetEngine:
         t = p + ".transformer_blocks.0"
         d1, d2 = a.h1() * 64, a.h2() * 64
         self._mark(p + ".norm.weight")
+        if self.train and self.group_wgrad:
+            self.tape.append(self._wg_flush)       # runs at the end of the block's backward, before the mark above
         n = self.groupnorm(x, p + ".norm", B, N, G, c // G, 1e-6, False)
         h = self.linear(n, p + ".proj_in", bias=p + ".proj_in.bias")
         l1 = self.layernorm(h, t + ".norm1")
@@ -664,7 +695,18 @@ class UNetEngine:
         l3 = self.layernorm(h, t + ".norm3")
         gl = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True)
         h = self.linear(gl, t + ".ff.net.2", bias=t + ".ff.net.2.bias", residual=h)
-        return self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out, cs=(B, N) if cs else None)
+        y = self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out, cs=(B, N) if cs else None)
+        if self.train and self.group_wgrad:
+            self.tape.append(self._wg_open)        # runs first in the block's backward
+        return y
+
+    def _wg_open(self):
+        self._wg_items = []
+
+    def _wg_flush(self):
+        items, self._wg_items = self._wg_items, None
+        if items:
+            k.wgrad_group(items, self.slabs)
 
     # ------------------------------------------------------------------ whole model
     def forward(self, x, timesteps, ehs, B, H, W, train):

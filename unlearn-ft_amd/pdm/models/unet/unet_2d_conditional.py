@@ -20,10 +20,32 @@ from .engine import UNetEngine, Act
 from .params import ParamStore, build_entries
 from .spec import UNetConfig, apply_arch_vector, gate_structure, padc
 
-_GATED_DOWN = ("CrossAttnDownBlock2DWidthHalfDepthGated", "DownBlock2DWidthHalfDepthGated",
-               "CrossAttnDownBlock2D", "DownBlock2D")
-_GATED_UP = ("CrossAttnUpBlock2DWidthHalfDepthGated", "UpBlock2DWidthHalfDepthGated", "CrossAttnUpBlock2D",
-             "UpBlock2D")
+# Block-type STRINGS the YAML recipes carry (`model.prediction_model.unet_down_blocks / unet_up_blocks`) are the factory names
+# of get_down_block / get_up_block (pdm/models/unet/unet_2d_conditional.py:90-243, 382-502): "...HalfGated" selects the
+# *WidthHalfDepthGated container class (:119-132, :217-242, :397-410, :477-502), the plain names the diffusers blocks (the
+# teacher); a leading "UNetRes" is stripped (:90, :382).  The container class names themselves are accepted as aliases.
+# value: does the stage carry transformers
+_GATED_DOWN = {"CrossAttnDownBlock2DHalfGated": True, "DownBlock2DHalfGated": False,
+               "CrossAttnDownBlock2DWidthHalfDepthGated": True, "DownBlock2DWidthHalfDepthGated": False,
+               "CrossAttnDownBlock2D": True, "DownBlock2D": False}
+_GATED_UP = {"CrossAttnUpBlock2DHalfGated": True, "UpBlock2DHalfGated": False,
+             "CrossAttnUpBlock2DWidthHalfDepthGated": True, "UpBlock2DWidthHalfDepthGated": False,
+             "CrossAttnUpBlock2D": True, "UpBlock2D": False}
+
+
+def _check_block_types(names, allowed, attn_stages, what):
+    """The engine's topology is the one every shipped recipe selects; a recipe that names another one is an error, not a
+    silently different model."""
+    if not names:
+        return
+    names = [n[7:] if n.startswith("UNetRes") else n for n in names]
+    for nme in names:
+        if nme not in allowed:
+            raise ValueError(f"block type {nme!r} is not supported by the MI355X engine (supported: {tuple(allowed)}; the "
+                             f"fully depth-gated '...2DGated' containers are not used by any shipped config)")
+    got = tuple(allowed[n] for n in names)
+    if got != tuple(attn_stages):
+        raise ValueError(f"{what}={names}: transformer stages {got} differ from the engine's topology {tuple(attn_stages)}")
 
 
 class _BlockHandle:
@@ -70,12 +92,10 @@ class UNet2DConditionModelPruned:
                         gated_ff=True, ff_gate_width=32, unet_config=None, torch_dtype=torch.bfloat16, device=None,
                         train=True, seed=0, **unused):
         cfg = unet_config or UNetConfig.sd21()
-        for names, allowed in ((down_block_types, _GATED_DOWN), (up_block_types, _GATED_UP)):
-            for nme in names or ():
-                if nme not in allowed:
-                    raise ValueError(f"block type {nme!r} is not supported by the MI355X engine "
-                                     f"(supported: {allowed}; the *WidthDepthGated containers are not used by any "
-                                     f"shipped config)")
+        _check_block_types(down_block_types, _GATED_DOWN, cfg.attn_stages_down, "down_block_types")
+        _check_block_types(up_block_types, _GATED_UP, cfg.attn_stages_up, "up_block_types")
+        if mid_block_type not in (None, "UNetMidBlock2DCrossAttnWidthGated", "UNetMidBlock2DCrossAttn"):
+            raise ValueError(f"mid_block_type {mid_block_type!r} is not supported by the MI355X engine")
         if ff_gate_width != cfg.ff_gate_width:
             cfg = UNetConfig(**{**cfg.__dict__, "ff_gate_width": ff_gate_width})
         if not gated_ff:
