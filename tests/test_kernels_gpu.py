@@ -928,16 +928,16 @@ def test_layernorm_bwd_extra_addend(dev, dn, C, M):
 
 def test_wgrad_group_of_a_transformer_block_matches_separate_launches(dev):
     """pdm._pdmk.wgrad_group: the eight Linear weight gradients of one transformer block (one reduction length, outputs from
-    [208, 208] to [1664, 208], two of them with a bias gradient) as grouped launches with ONE split factor against the same
+    [224, 224] to [1792, 224], two of them with a bias gradient) as grouped launches with ONE split factor against the same
     gradients computed one by one (k.wgrad, each with its own plan) and against fp32 torch; a second group of another reduction
     length in the same call.  Same arithmetic up to the fp32 summation order."""
     from pdm import _pdmk as k
     torch.manual_seed(31)
     dt = torch.bfloat16
     P1, P2 = 4096, 1024
-    shapes = [(624, 208, P1, True), (208, 208, P1, True), (208, 208, P1, False), (208, 208, P1, True), (1664, 208, P1, True),
-              (208, 832, P1, True), (208, 208, P1, True), (208, 208, P1, False), (320, 320, P2, True), (320, 640, P2, False),
-              (224, 96, P2, True)]
+    shapes = [(672, 224, P1, True), (224, 224, P1, True), (224, 224, P1, False), (224, 224, P1, True), (1792, 224, P1, True),
+              (224, 896, P1, True), (224, 224, P1, True), (224, 224, P1, False), (320, 320, P2, True), (320, 640, P2, False),
+              (224, 96, P2, True)]      # (the engine pads pruned widths to multiples of 32: 224 = a 208-channel layer)
     items, refs, seps, q = [], [], [], k.SlabQueue()
     for No, Ki, P, has_bias in shapes:
         dy, x = rnd((P, No), dev, dt), rnd((P, Ki), dev, dt)
@@ -1390,6 +1390,32 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
     acc = torch.zeros(Bn, 4, N, device=dev, dtype=torch.int64)
     k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc, 0))
     check(acc, 0, y, Bn, rows, "huge activations")
+    # a NaN / inf in the tensor must give non-finite statistics for ITS (image, group) - as the statistics pass does - and leave every
+    # other group exact: the non-finite partial sets a flag bit in the column's sum-of-squares limb (common.h cs_add), whatever else
+    # is added to that column before or after
+    Bn, rows, N, K = 2, 128, 64, 64
+    for poison in (float("nan"), float("inf")):
+        a = rnd((Bn * rows, K), dev, dt)
+        a[rows + 5, 9] = poison                                       # image 1, column 9 -> group 9 // 2 = 4
+        y = torch.zeros(Bn * rows, N, device=dev, dtype=dt)
+        acc = torch.zeros(Bn, 4, N, device=dev, dtype=torch.int64)
+        for _ in range(2):                                            # the flag survives later finite additions to the column
+            k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc, 0))
+        G, gs = 32, 2
+        gamma, beta = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+        z = torch.zeros_like(y)
+        st = torch.zeros(Bn, G, 2, device=dev)
+        acc1 = torch.zeros_like(acc)
+        k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc1, 0))
+        k.groupnorm_apply_colstat(y, z, gamma, beta, st, acc1, 0, Bn, rows, N, N, N, G, gs, 1e-5, False)
+        bad = ~torch.isfinite(st).all(dim=2)
+        want = torch.zeros(Bn, G, dtype=torch.bool, device=dev)
+        want[1, 4] = True
+        assert torch.equal(bad, want), (poison, bad.nonzero().tolist())
+        st0 = torch.zeros_like(st)
+        k.groupnorm_fwd(y, torch.zeros_like(y), gamma, beta, st0, k.groupnorm_ws(dev, Bn, G), Bn, rows, N, N, N, G, gs, 1e-5, False)
+        good = ~want
+        close(st[good], st0[good], 1e-4, "statistics of the clean groups beside a non-finite one")
     # shapes the epilogue does not take are refused (-1), never silently skipped
     y = torch.zeros(96, 64, device=dev, dtype=dt)
     with pytest.raises(k.PdmkError):

@@ -759,8 +759,13 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
     }
     constexpr bool is_bf16 = std::is_same<T, bf16>::value;
     const int want_dq = f_dq ? f_dq : forced, want_dkv = f_dkv ? f_dkv : forced;
-    const bool wide_dq = want_dq ? want_dq == 2 : (is_bf16 && (long)((Nq + 127) / 128) * H * B >= 384 && Nk >= 256);
-    const bool wide_dkv = want_dkv ? want_dkv == 2 : (is_bf16 && (long)((Nk + 127) / 128) * H * B >= 384 && Nq >= 256);
+#ifdef PDMK_ATTN_AGPR      // built without -amdgpu-mfma-vgpr-form (csrc/Makefile probe): the narrow forms are the faster ones there
+    const bool auto_wide = false;
+#else
+    const bool auto_wide = true;
+#endif
+    const bool wide_dq = want_dq ? want_dq == 2 : (auto_wide && is_bf16 && (long)((Nq + 127) / 128) * H * B >= 384 && Nk >= 256);
+    const bool wide_dkv = want_dkv ? want_dkv == 2 : (auto_wide && is_bf16 && (long)((Nk + 127) / 128) * H * B >= 384 && Nq >= 256);
     if (wide_dq)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 2>), dim3((Nq + 127) / 128, H, B), dim3(NT), 0, st, PDMK_DQ_ARGS);
     else

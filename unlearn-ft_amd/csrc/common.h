@@ -62,9 +62,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // Kernel-argument block of a grouped GEMM launch (pdmk_gemm_group): problem i owns the linear workgroup ids
 // [start[i], start[i] + gx[i] * gy[i]) (start[] are multiples of 8; the gap is padding workgroups that exit at once).
 // pdmk_gemm_args.colstat: one workgroup's partial sum -> the fixed-point accumulator (30 fraction bits, two 64-bit limbs at
-// `lo` and `lo + cs_ld`; integer atomics, no return value).  value * 2^30 = hi * 2^32 + low with low in [0, 2^32): both limbs
-// have > 2^20 additions of headroom, and their totals do not depend on the order of the additions.
-__device__ __forceinline__ void cs_add(int64_t* lo, int cs_ld, float sum) {
+// `lo` and `lo + cs_ld`; integer atomics, no return value).  value * 2^30 = hi * 2^32 + low with low in [0, 2^32); the totals
+// do not depend on the order of the additions.  Headroom: the low limb takes 2^32 additions; a partial at the clamp (2^56) puts
+// 2^54 into the high limb, which then takes 2^9 such additions before its sign bit - real partial sums (|x| <= 3e38 is not, |x|
+// of an SD U-Net activation <= ~1e4 over <= 2^12 rows per workgroup is) leave > 2^30.
+// A non-finite partial (NaN / inf from an overflowed activation) must stay visible: fmaxf(NaN, x) would return x and the clamp
+// would turn it into a large finite number, i.e. finite GroupNorm statistics for a tensor that holds a NaN.  It sets bit 62 of
+// the HIGH LIMB OF THE SUM OF SQUARES of its column instead (atomic OR: idempotent, and that limb only ever receives non-negative
+// additions far below 2^62, so the bit survives whatever arrives before or after it); the reader (gn_apply's statistics prologue)
+// tests the bit per column with cs_flagged() and reports NaN statistics for the group.  sq: this call adds to the sum-of-squares
+// rows (2 / 3) of the accumulator, else to the sum rows (0 / 1).
+constexpr long long CS_NONFINITE = 1ll << 62;
+__device__ __forceinline__ void cs_add(int64_t* lo, int cs_ld, float sum, bool sq) {
+    if (!(fabsf(sum) <= 3.0e38f)) {                                   // NaN or inf
+        atomicOr(reinterpret_cast<unsigned long long*>(lo + (sq ? 1 : 3) * cs_ld), (unsigned long long)CS_NONFINITE);
+        return;
+    }
     sum = fminf(fmaxf(sum, -7.2e16f), 7.2e16f);                       // 2^56: keeps the high limb inside 64 bits
     const double d = (double)sum * PDMK_COLSTAT_SCALE;                // exact (power of two)
     const double hd = floor(d * (1.0 / 4294967296.0));
@@ -73,6 +86,9 @@ __device__ __forceinline__ void cs_add(int64_t* lo, int cs_ld, float sum) {
     atomicAdd(reinterpret_cast<unsigned long long*>(lo), low);
     atomicAdd(reinterpret_cast<unsigned long long*>(lo + cs_ld), (unsigned long long)hi);
 }
+// a sum-of-squares high limb as read back: was a non-finite partial added to this column?  (strip the bit before summing limbs)
+__device__ __forceinline__ bool cs_flagged(long long sq_hi) { return (sq_hi & CS_NONFINITE) != 0; }
+__device__ __forceinline__ long long cs_strip(long long sq_hi) { return sq_hi & ~CS_NONFINITE; }
 // the value of one accumulator column (limbs already summed over a group's columns or not)
 __device__ __forceinline__ double cs_value(long long low, long long hi) {
     return ((double)hi * 4294967296.0 + (double)low) * (1.0 / PDMK_COLSTAT_SCALE);

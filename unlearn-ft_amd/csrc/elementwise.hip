@@ -628,7 +628,7 @@ __global__ __launch_bounds__(NT) void splitk_finish_cs_kernel(const float* __res
             float sum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sum += part[r][which][col];
-            cs_add(colstat + ((m0 / rows_per_b) * 4 + which * 2) * cs_ld + nn, cs_ld, sum);
+            cs_add(colstat + ((m0 / rows_per_b) * 4 + which * 2) * cs_ld + nn, cs_ld, sum, which == 1);
         }
     }
 }

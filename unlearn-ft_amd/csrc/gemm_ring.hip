@@ -330,7 +330,7 @@ __device__ __forceinline__ void ring_epilogue(const pdmk_gemm_args& g, const LC 
                         float sum = 0.f;
 #pragma unroll
                         for (int r = 0; r < RS; ++r) sum += stage[r * (2 * BN) + c];
-                        cs_add(g.colstat + ((long)img * 4 + (c < BN ? 0 : 2)) * g.cs_ld + g.cs_col0 + n0 + col, g.cs_ld, sum);
+                        cs_add(g.colstat + ((long)img * 4 + (c < BN ? 0 : 2)) * g.cs_ld + g.cs_col0 + n0 + col, g.cs_ld, sum, c >= BN);
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) cs1[r] = cs2[r] = 0.f;

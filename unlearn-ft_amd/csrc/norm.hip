@@ -202,6 +202,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
     const bool vec_gb = ((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0;
     // (the statistics' own loads are the very first: loads return in issue order, so behind the row sweep they would wait for it)
     long long l0 = 0, h0 = 0, l1 = 0, h1 = 0;
+    int cs_bad = 0;
     if (nblk < 0 && (tid >> 2) < G) {
         // epilogue statistics (pdmk_gemm_args.colstat): `part` = this tensor's first column of the [B][4][cs_ld] per-(image, column)
         // fixed-point sums (two limbs each); group g = its gs columns.  4 threads per group (G <= 64): thread (g, p) adds the limbs of
@@ -210,10 +211,12 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
         const long long* cg = reinterpret_cast<const long long*>(part) + (long)b * 4 * cs_ld + (tid >> 2) * gs;
 #pragma unroll 4
         for (int j = tid & 3; j < gs; j += 4) {
+            const long long q3 = cg[3 * cs_ld + j];
             l0 += cg[j];
             h0 += cg[cs_ld + j];
             l1 += cg[2 * cs_ld + j];
-            h1 += cg[3 * cs_ld + j];
+            h1 += cs_strip(q3);
+            cs_bad |= cs_flagged(q3) ? 1 : 0;                   // a producer's partial sum was NaN / inf (common.h cs_add)
         }
     }
     float gmv[SLOTS][V], btv[SLOTS][V];
@@ -252,21 +255,25 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, T
             l1 += __shfl_xor(l1, m, 64);
             h1 += __shfl_xor(h1, m, 64);
         }
-        if (g < G && pth == 0) {
-            d0[g] = cs_value(l0, h0);
-            d1[g] = cs_value(l1, h1);
+        cs_bad |= __shfl_xor(cs_bad, 1, 64);
+        cs_bad |= __shfl_xor(cs_bad, 2, 64);
+        if (g < G && pth == 0) {                                 // non-finite input -> non-finite statistics, as a statistics pass gives
+            d0[g] = cs_bad ? __builtin_nan("") : cs_value(l0, h0);
+            d1[g] = cs_bad ? __builtin_nan("") : cs_value(l1, h1);
         }
         __syncthreads();
     } else {
         gn_sum_slabs(part, b, nblk, G, d0, d1, scr);
     }
     if (tid < G) {
-        // (double only where the cancellation is: E[x^2] - mean^2.  The division and the square root are fp32 - 1 / n by one v_rcp
-        // refined once, rsqrt by v_rsq refined once: the fp64 div + sqrt they replace were ~1 us of every block's prologue)
-        const float nf = (float)HW * (float)gs;
-        float rn = __frcp_rn(nf);
-        rn = rn * (2.0f - nf * rn);
-        const double inv_n = (double)rn;
+        // (double where the cancellation is: E[x^2] - mean^2 - INCLUDING 1 / n, whose error multiplies mean^2: the fp32 v_rcp seeds
+        // it and two Newton steps in double bring it to ~1e-16 relative (a 6e-8 inv_n would leave 6e-8 * mean^2 / var in the
+        // variance of a channel group with |mean| >> std - ADVICE r3).  Only the square root stays fp32 - v_rsq refined once: the
+        // fp64 div + sqrt this replaces were ~1 us of every block's prologue, two double fma pairs are not)
+        const double nd = (double)HW * (double)gs;
+        double inv_n = (double)__frcp_rn((float)nd);
+        inv_n = inv_n * (2.0 - nd * inv_n);
+        inv_n = inv_n * (2.0 - nd * inv_n);
         const double mean = d0[tid] * inv_n;
         double var = d1[tid] * inv_n - mean * mean;
         if (var < 0) var = 0;
