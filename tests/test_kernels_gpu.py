@@ -1396,26 +1396,29 @@ def test_gemm_groupnorm_statistics_epilogue(dev, force_cfg, cand):
     Bn, rows, N, K = 2, 128, 64, 64
     for poison in (float("nan"), float("inf")):
         a = rnd((Bn * rows, K), dev, dt)
-        a[rows + 5, 9] = poison                                       # image 1, column 9 -> group 9 // 2 = 4
-        y = torch.zeros(Bn * rows, N, device=dev, dtype=dt)
-        acc = torch.zeros(Bn, 4, N, device=dev, dtype=torch.int64)
-        for _ in range(2):                                            # the flag survives later finite additions to the column
-            k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc, 0))
+        clean = torch.zeros(Bn * rows, N, device=dev, dtype=dt)
+        res = clean.clone()
+        res[rows + 5, 9] = poison                                     # ONE element: image 1, column 9 -> group 9 // 2 = 4
+        y, y2 = torch.zeros(Bn * rows, N, device=dev, dtype=dt), torch.zeros(Bn * rows, N, device=dev, dtype=dt)
         G, gs = 32, 2
         gamma, beta = torch.ones(N, device=dev), torch.zeros(N, device=dev)
         z = torch.zeros_like(y)
         st = torch.zeros(Bn, G, 2, device=dev)
-        acc1 = torch.zeros_like(acc)
-        k.gemm(a, w, y, Bn * rows, N, K, K, K, N, rows_per_b=rows, colstat=(acc1, 0))
+        acc1 = torch.zeros(Bn, 4, N, device=dev, dtype=torch.int64)
+        # finite additions to the same columns before and after the poisoned launch: the flag must survive both
+        for R_ in (clean, res, clean):
+            k.gemm(a, w, y if R_ is res else y2, Bn * rows, N, K, K, K, N, R=R_, ldr=N, rows_per_b=rows, colstat=(acc1, 0))
+        assert not torch.isfinite(y[rows + 5, 9]) and torch.isfinite(y2).all()
         k.groupnorm_apply_colstat(y, z, gamma, beta, st, acc1, 0, Bn, rows, N, N, N, G, gs, 1e-5, False)
         bad = ~torch.isfinite(st).all(dim=2)
         want = torch.zeros(Bn, G, dtype=torch.bool, device=dev)
         want[1, 4] = True
         assert torch.equal(bad, want), (poison, bad.nonzero().tolist())
         st0 = torch.zeros_like(st)
-        k.groupnorm_fwd(y, torch.zeros_like(y), gamma, beta, st0, k.groupnorm_ws(dev, Bn, G), Bn, rows, N, N, N, G, gs, 1e-5, False)
+        k.groupnorm_fwd(y2, torch.zeros_like(y), gamma, beta, st0, k.groupnorm_ws(dev, Bn, G), Bn, rows, N, N, N, G, gs, 1e-5, False)
         good = ~want
-        close(st[good], st0[good], 1e-4, "statistics of the clean groups beside a non-finite one")
+        # (three launches were added with n counted once: the clean groups' "mean" is 3 x the mean of one tensor)
+        close(st[good][:, 0], 3 * st0[good][:, 0], 1e-4, "sums of the clean groups beside a non-finite one")
     # shapes the epilogue does not take are refused (-1), never silently skipped
     y = torch.zeros(96, 64, device=dev, dtype=dt)
     with pytest.raises(k.PdmkError):

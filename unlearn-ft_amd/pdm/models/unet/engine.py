@@ -452,10 +452,13 @@ class UNetEngine:
         self.gn_miss = [] if os.environ.get("PDMK_GN_EPI_DEBUG") else None    # (layer, rows, columns) of GroupNorms without them
         if not self.gn_epi:
             return
-        if self._cs_need and (self._cs_arena is None or self._cs_arena.numel() < self._cs_need):
+        # sized for the LARGEST pass seen so far (the teacher alternates B and 2B passes): after one eager pass of every shape -
+        # the warm-up that precedes any capture - the arena never grows again, so no capture allocates or zero-fills piecemeal
+        self._cs_max = max(getattr(self, "_cs_max", 0), self._cs_need)
+        if self._cs_max and (self._cs_arena is None or self._cs_arena.numel() < self._cs_max):
             # grow: the old arena is RETAINED - a captured graph of an earlier (smaller) pass still zeroes and adds into it
             self._cs_old.append(self._cs_arena)
-            self._cs_arena = torch.empty(max(self._cs_need, 1 << 16), device=self.dev, dtype=torch.int64)
+            self._cs_arena = torch.empty(max(self._cs_max, 1 << 16), device=self.dev, dtype=torch.int64)
         self._cs_off, self._cs_need = 0, 0
         self._cs_views, self._cs_cats = {}, {}
         self.gn_count = [0, 0]          # GroupNorms of this pass, of which with statistics from a producer's epilogue
@@ -486,9 +489,12 @@ class UNetEngine:
                 y.stride(0) % 8 == 0 and y.dtype == torch.bfloat16):
             return None
         if view:
+            # keyed by the view's address, and checked against the concat buffer it was registered for (which the entry keeps
+            # alive, so the address cannot be recycled inside the pass): same rows, same row stride, columns inside the buffer
             ent = self._cs_views.get(y.data_ptr())
-            if ent is not None and ent[0].shape[0] == B and ent[1] + N <= ent[0].shape[2]:
-                return ent
+            if (ent is not None and ent[0].shape[0] == B and ent[1] + N <= ent[0].shape[2] and ent[2].shape[0] == y.shape[0] and
+                    ent[2].stride(0) == y.stride(0)):
+                return ent[0], ent[1]
         return self._cs_alloc(B, N), 0
 
     def groupnorm(self, x, key, B, HW, G, gs, eps, silu):
@@ -631,9 +637,9 @@ class UNetEngine:
         if self.gn_epi and self._cs_shape_ok(M, B, ch + C) and self.dtype == torch.bfloat16:
             acc = self._cs_alloc(B, ch + C)
             self._cs_cats[cat.data_ptr()] = acc
-            self._cs_views[view.data_ptr()] = (acc, ch)
+            self._cs_views[view.data_ptr()] = (acc, ch, cat)
             if ch:
-                self._cs_views[cat.data_ptr()] = (acc, 0)
+                self._cs_views[cat.data_ptr()] = (acc, 0, cat)
         return cat, view
 
     @staticmethod
