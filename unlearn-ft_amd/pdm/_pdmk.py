@@ -548,7 +548,11 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
          accumulate=(sk == 1), dtype=dt(x), macs=macs, colsum_out=colsum_out)
 
 
-def wgrad_group(items, queue, target_wgs=512):
+_WG_TARGET = int(os.environ.get("PDMK_WG_TARGET", "512"))     # workgroups a block's grouped weight-gradient launch aims for
+_WG_MINK = int(os.environ.get("PDMK_WG_MINK", "32"))           # and the fewest 64-row K-steps a split may be left with
+
+
+def wgrad_group(items, queue, target_wgs=None):
     """The Linear weight gradients of one transformer block (blocks.py:705-867 backward: to_q/k/v, to_out, ff.net.0.proj,
     ff.net.2, proj_in, proj_out reached from accelerator.backward, trainer.py:2782) as grouped launches (pdmk_gemm_group): every
     item reduces over the SAME K pixel rows into a small [M, N] output, so one problem alone fills the 256 CUs only by cutting its
@@ -563,7 +567,7 @@ def wgrad_group(items, queue, target_wgs=512):
         items = [it for it in items if not any(it is s_ for s_ in same)]
         tiles = sum(((it[3] + 127) // 128) * ((it[4] + 127) // 128) for it in same)
         nk = max(1, K // 64)
-        sk = max(1, min(target_wgs // max(tiles, 1), nk // 32, 64))
+        sk = max(1, min((target_wgs or _WG_TARGET) // max(tiles, 1), nk // _WG_MINK, 64))
         if len(same) == 1 or queue is None:
             for dy, x, dW, M, N, K_, lda, ldb, cs, macs in same:
                 wgrad(dy, x, dW, M, N, K_, lda, ldb, colsum_out=cs, macs=macs, queue=queue)
