@@ -410,11 +410,12 @@ def main():
                 members = shp if isinstance(shp, list) else [shp]       # a grouped launch lists its problems
                 byts = mflop = 0.0
                 ti = 0.0
-                for (M, N, K, sk) in members:
+                for (M, N, K, sk, *rd) in members:
                     if wg:      # C[M,N] fp32 += dY[K,M]^T X[K,N]   (conv: X is the image, N = 9 Ci)
                         byts += esz * (K * M + K * (N // 9 if kind[2] == 2 else N)) + 4 * M * N
-                    else:
-                        byts += esz * (M * (K // 9 if conv_a else K) + N * K + M * N)
+                    else:       # + the residual / the previous output an accumulating epilogue reads (round 4: it was left out,
+                        # which overstated the dominant kernel's traffic_ratio - half of its launches carry a residual)
+                        byts += esz * (M * (K // 9 if conv_a else K) + N * K + M * N * (2 if (rd and rd[0]) else 1))
                     mflop += 2.0 * M * N * K
                     # third side: what a CU can take in from L2 into LDS (~70 GB/s per CU, 18 TB/s chip-wide: MI355X_MICROARCH.md
                     # "Indexed rows: gather into LDS", tools/small_gemm_sweep.py).  An output tile BM x BN needs (BM + BN) K

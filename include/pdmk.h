@@ -103,7 +103,24 @@ typedef struct pdmk_gemm_args {
                             out_f32; LDS-DMA ring and halo kernels only */
     int32_t cs_ld;       /* elements per accumulator row (>= cs_col0 + N: a concat buffer's accumulator has one row for all its columns) */
     int32_t cs_col0;     /* accumulator column of output column 0 */
+    /* LayerNorm in the GEMM's prologue (round 4; BasicTransformerBlock's norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q, norm3 ->
+     * ff.net.0.proj, blocks.py:705-867 with the leaves of (D) BasicTransformerBlock.forward): ln_gamma != NULL makes the GEMM
+     * multiply LayerNorm(A) instead of A - every row of A normalised over its K columns (mean and the variance of the deviations
+     * in fp32, eps = ln_eps), scaled by ln_gamma[k], shifted by ln_beta[k] and rounded to bf16 exactly as pdmk_layernorm_fwd
+     * stores it - while the row block sits in registers, so the normalised tensor needs no pass of its own.  ln_stats (optional,
+     * [M][2] fp32: mean, rstd - what pdmk_layernorm_bwd reads) and ln_out (optional, [M][ld_ln_out] bf16: the normalised rows, the
+     * B operand of this Linear's weight gradient) are written when the caller trains.  A_ROWK x B_ROWK, bf16, K % 8 == 0 and
+     * K <= 640, splitk 1, no colstat; served by the row-block kernel only: -2 where it does not take the shape (the caller
+     * then runs pdmk_layernorm_fwd and the GEMM as two launches; pdmk_gemm_ln_supported answers beforehand). */
+    const float* ln_gamma;
+    const float* ln_beta;
+    float* ln_stats;
+    void* ln_out;
+    int32_t ld_ln_out;
+    float ln_eps;
 } pdmk_gemm_args;
+/* 1 when pdmk_gemm takes `args` (ln_gamma set) as ONE launch, 0 when the caller has to run the LayerNorm by itself. */
+int pdmk_gemm_ln_supported(const pdmk_gemm_args* args);
 
 /* PDMK_EPI_GEGLU (GEGLUGated.forward, pdm/models/unet/blocks.py:44-59 = Linear -> chunk -> hidden * gelu_erf(gate)), fused
  * into the projection's epilogue: the N GEMM columns hold (hidden, gate) INTERLEAVED in blocks of 8 - columns

@@ -766,6 +766,84 @@ def test_rowblock_linear(dev, force_cfg, cand, grp):
         os.environ.pop("PDMK_RB_GRP", None)
 
 
+@pytest.mark.parametrize("grp", [0, 1, 3])
+def test_layernorm_in_the_gemm_prologue(dev, grp):
+    """pdmk_gemm_args.ln_gamma: LayerNorm(A) @ W^T (+ bias, + the GEGLU epilogue) as ONE launch of the row-block kernel - the row
+    block is normalised in registers - against pdmk_layernorm_fwd followed by the same GEMM (forced row-block candidate: the
+    normalised operand differs only where the two kernels' fp32 row sums round differently, so the products agree to bf16
+    resolution) and against fp32 torch; the optional outputs of the training path (mean / rstd and the normalised rows) against
+    pdmk_layernorm_fwd's; ragged M, K below the register image (zero-padded chunks must stay zero), several column groups, a
+    strided A.  BasicTransformerBlock norm1 -> to_q/k/v, norm2 -> to_q, norm3 -> ff.net.0.proj (blocks.py:705-867)."""
+    import os
+    from pdm import _pdmk as k
+    torch.manual_seed(77)
+    dt = torch.bfloat16
+    if grp:
+        os.environ["PDMK_RB_GRP"] = str(grp)
+    try:
+        for M, N, K, lda, mode in ((300, 320, 320, 320, "plain"), (4096, 960, 320, 328, "plain"), (1024, 640, 640, 640, "bias"),
+                                   (515, 352, 256, 264, "bias"), (2048, 512, 320, 320, "geglu"), (1000, 1408, 320, 320, "geglu+keep"),
+                                   (256, 1920, 640, 640, "plain"), (64, 8, 32, 32, "bias")):
+            A = (rnd((M, lda), dev, dt) * 1.7 + 0.4)
+            W = rnd((N, K), dev, dt, K ** -0.5)
+            gamma, beta = torch.randn(K, device=dev) * 0.3 + 1, torch.randn(K, device=dev) * 0.3
+            bias = torch.randn(N, device=dev) if ("bias" in mode or "geglu" in mode) else None
+            geglu = "geglu" in mode
+            assert k.gemm_ln_supported(A, W, M, N, K, lda, K, geglu=geglu, bias=bias is not None), (M, N, K, mode)
+            # two launches: LayerNorm, then the GEMM through the same kernel family
+            ln_ref = torch.zeros(M, K, device=dev, dtype=dt)
+            st_ref = torch.zeros(M, 2, device=dev)
+            k.layernorm_fwd(A, ln_ref, gamma, beta, st_ref, M, K, lda, K, 1e-5)
+            st, lno = torch.zeros(M, 2, device=dev), torch.full((M, K + 8), 5.0, device=dev, dtype=dt)
+            ln = (gamma, beta, st, lno, 1e-5)
+            os.environ["PDMK_RING_CFG"] = "20" if K <= 320 else "21"
+            try:
+                if geglu:
+                    gl0, gl1 = torch.zeros(M, N // 2, device=dev, dtype=dt), torch.zeros(M, N // 2, device=dev, dtype=dt)
+                    pre0 = torch.zeros(M, N, device=dev, dtype=dt) if "keep" in mode else None
+                    pre1 = torch.zeros(M, N, device=dev, dtype=dt) if "keep" in mode else None
+                    assert k.gemm_geglu(ln_ref, W, gl0, pre0, M, N, K, K, K, bias=bias)
+                    assert k.gemm_geglu(A, W, gl1, pre1, M, N, K, lda, K, bias=bias, ln=ln)
+                    y0, y1 = gl0, gl1
+                    z = ln_ref.float() @ W.float().t() + bias
+                    zz = z.reshape(M, N // 16, 2, 8).to(dt).float()
+                    ref = (zz[:, :, 0] * F.gelu(zz[:, :, 1])).reshape(M, N // 2)
+                    if pre0 is not None:
+                        close(pre1, pre0, 1e-2, "pre-activation copy")
+                else:
+                    y0, y1 = torch.zeros(M, N, device=dev, dtype=dt), torch.full((M, N + 8), 3.0, device=dev, dtype=dt)
+                    k.gemm(ln_ref, W, y0, M, N, K, K, K, N, bias=bias)
+                    k.gemm(A, W, y1, M, N, K, lda, K, N + 8, bias=bias, ln=ln)
+                    assert k.candidate_name(k.A_ROWK, k.B_ROWK, k.last_candidate()).startswith("pdmk_rb::rowblock_kernel")
+                    assert float((y1[:, N:].float() - 3.0).abs().max()) == 0.0
+                    y1 = y1[:, :N]
+                    ref = ln_ref.float() @ W.float().t() + (bias if bias is not None else 0.0)
+            finally:
+                os.environ.pop("PDMK_RING_CFG", None)
+            close(y1, ref, 2e-2, f"LN-prologue GEMM vs fp32 {M}x{N}x{K} {mode}")
+            close(y1, y0, 6e-3, f"LN-prologue GEMM vs LayerNorm + GEMM {M}x{N}x{K} {mode}")
+            close(st, st_ref, 1e-5, "mean / rstd from the prologue")
+            close(lno[:, :K], ln_ref, 8e-3, "normalised rows from the prologue")         # <= one bf16 ulp where the sums round apart
+            mism = (lno[:, :K] != ln_ref).float().mean().item()
+            assert mism < 0.02, mism                                                      # ... and only on a few elements
+            assert float((lno[:, K:].float() - 5.0).abs().max()) == 0.0                  # columns past K untouched
+            # inference form: no statistics, no normalised rows
+            y2 = torch.zeros_like(y1)
+            if geglu:
+                assert k.gemm_geglu(A, W, y2, None, M, N, K, lda, K, bias=bias, ln=(gamma, beta, None, None, 1e-5))
+            else:
+                k.gemm(A, W, y2, M, N, K, lda, K, N, bias=bias, ln=(gamma, beta, None, None, 1e-5))
+            assert torch.equal(y2, y1.contiguous())
+        # shapes the row-block kernel does not take are refused (-2), never computed without the LayerNorm
+        A, W = rnd((256, 1280), dev, dt), rnd((320, 1280), dev, dt)
+        assert not k.gemm_ln_supported(A, W, 256, 320, 1280, 1280, 1280)
+        with pytest.raises(k.PdmkError):
+            k.gemm(A, W, torch.zeros(256, 320, device=dev, dtype=dt), 256, 320, 1280, 1280, 1280, 320,
+                   ln=(torch.ones(1280, device=dev), torch.zeros(1280, device=dev), None, None, 1e-5))
+    finally:
+        os.environ.pop("PDMK_RB_GRP", None)
+
+
 def _interleave8(h, g):
     """[.., F] hidden and gate -> [.., 2F] with (hidden, gate) interleaved in blocks of 8 columns (PDMK_EPI_GEGLU layout)."""
     F_ = h.shape[-1]

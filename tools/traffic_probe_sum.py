@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """usage: traffic_probe_sum.py <probe stdout> <fetch_dir> <write_dir>: per variant of tools/traffic_probe.py the HBM bytes per launch."""
 import csv, glob, re, sys
-variants = [dict(kv.split("=", 1) for kv in l.split()[1:]) for l in open(sys.argv[1]) if l.startswith("VARIANT")]
+variants = []
+for l in open(sys.argv[1]):
+    if l.startswith("VARIANT"):
+        head, kern = l.split(" kernel=", 1)
+        v = dict(kv.split("=", 1) for kv in head.split()[1:])
+        v["kernel"] = kern.strip()
+        variants.append(v)
 def load(d):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

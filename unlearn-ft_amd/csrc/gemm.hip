@@ -848,12 +848,37 @@ static int validate_args(const pdmk_gemm_args& g) {
     return 0;
 }
 
+int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id, bool dry);   // gemm_rowblock.hip
+int pdmk_gemm_rowblock_num_configs();
+// LayerNorm prologue (pdmk_gemm_args.ln_gamma): the row-block candidate whose register image holds K, or -1
+static int ln_candidate(const pdmk_gemm_args& g, long* ab, long* bb) {
+    if (g.dtype != PDMK_BF16 || g.a_mode != PDMK_A_ROWK || g.b_mode != PDMK_B_ROWK || g.splitk > 1 || g.colstat || g.out_f32 ||
+        !ring_mode() || !operand_bytes(g, ab, bb))
+        return -1;
+    for (int id = 0; id < pdmk_gemm_rowblock_num_configs(); ++id)
+        if (pdmk_gemm_rowblock_launch(g, nullptr, *ab, *bb, id, true) == 0) return id;
+    return -1;
+}
+extern "C" int pdmk_gemm_ln_supported(const pdmk_gemm_args* a) {
+    if (!a || !a->ln_gamma || validate_args(*a)) return 0;
+    long ab, bb;
+    return ln_candidate(*a, &ab, &bb) >= 0 ? 1 : 0;
+}
+
 extern "C" int pdmk_gemm(const pdmk_gemm_args* a, pdmk_stream stream) {
     if (!a) return -1;
     const pdmk_gemm_args& g = *a;
     if (const int vrc = validate_args(g)) return vrc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     g_last_candidate = 0;
+    if (g.ln_gamma) {                                   // one kernel family serves it: no plan, no tuning
+        long ab, bb;
+        const int id = ln_candidate(g, &ab, &bb);
+        if (id < 0) return -2;
+        const int rc = pdmk_gemm_rowblock_launch(g, st, ab, bb, id, false);
+        g_last_candidate = 1 + pdmk_gemm_ring_num_configs() - pdmk_gemm_rowblock_num_configs() + id;
+        return rc == 1 ? -2 : rc;
+    }
     if (!(ring_eligible(g) && (g.K % 8) == 0) && !wgrad_eligible(g)) return launch_legacy(g, st);
     if ((g.a_mode == PDMK_A_COLK ? forced_wcfg() >= 0 : forced_cfg() >= 0) && !(g.epilogue && forced_cfg() == 0)) {
         const int rc = launch_candidate(g, st, g.a_mode == PDMK_A_COLK ? forced_wcfg() : forced_cfg());
@@ -1024,15 +1049,18 @@ int tune_group(const pdmk_gemm_args* a, int n, const int* ids, hipStream_t st) {
 extern "C" int pdmk_gemm_group(const pdmk_gemm_args* a, int n, pdmk_stream stream, int32_t* grouped_out) {
     if (grouped_out) *grouped_out = 0;
     if (!a || n < 1 || n > PDMK_GEMM_GROUP_MAX) return -1;
-    for (int i = 0; i < n; ++i)
+    bool any_ln = false;
+    for (int i = 0; i < n; ++i) {
         if (const int vrc = validate_args(a[i])) return vrc;
+        any_ln = any_ln || a[i].ln_gamma;
+    }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     auto separate = [&]() -> int {
         for (int i = 0; i < n; ++i)
             if (const int rc = pdmk_gemm(&a[i], stream)) return rc;
         return 0;
     };
-    if (n > 1 && forced_group() >= 1) {                 // tests: this candidate, grouped, no timing
+    if (n > 1 && forced_group() >= 1 && !any_ln) {                 // tests: this candidate, grouped, no timing
         const int rc = group_launch(a, n, st, forced_group());
         if (rc == 0) {
             g_last_candidate = forced_group();
@@ -1041,7 +1069,7 @@ extern "C" int pdmk_gemm_group(const pdmk_gemm_args* a, int n, pdmk_stream strea
         }
         return rc == 1 ? separate() : rc;
     }
-    if (n == 1 || !group_mode() || !ring_mode() || forced_cfg() >= 0 || forced_wcfg() >= 0) return separate();
+    if (n == 1 || any_ln || !group_mode() || !ring_mode() || forced_cfg() >= 0 || forced_wcfg() >= 0) return separate();
     bool fw = true, wg = true;
     for (int i = 0; i < n; ++i) {
         fw = fw && ring_eligible(a[i]) && (a[i].K % 8) == 0 && (a[i].a_mode == a[0].a_mode);

@@ -1109,7 +1109,7 @@ constexpr int kNumHalo = 4;      // halo-conv candidates follow the ring shapes 
 // row-block Linear kernels (gemm_rowblock.hip): candidate ids after every ring / halo shape
 int pdmk_gemm_rowblock_num_configs();
 int pdmk_gemm_rowblock_name(int id, char* buf, int n);
-int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id);
+int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id, bool dry = false);
 static int conv_halo_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
     using namespace pdmk_ring;
     const int tw = halo_tile_w(g, id, g.splitk);
@@ -1178,6 +1178,7 @@ int pdmk_gemm_ring_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes,
     using namespace pdmk_ring;
     if (g.dtype != PDMK_BF16 || g.b_mode != PDMK_B_ROWK || g.a_mode == PDMK_A_COLK) return 1;
     if ((g.K % 8) || (g.a_mode == PDMK_A_CONV && (g.conv_ci % 8))) return 1;
+    if (g.ln_gamma && id < kNumConfigs + kNumHalo) return 1;         // LayerNorm prologue: the row-block kernel only
     if (id >= kNumBase && id < kNumBase + kNumHalo) return conv_halo_launch(g, st, a_bytes, b_bytes, id - kNumBase);
     if (g.a_mode == PDMK_A_CONV && g.conv_mode >= 5) return 1;       // 2x2 phase convs: halo kernels only
     if (id >= kNumConfigs + kNumHalo) return pdmk_gemm_rowblock_launch(g, st, a_bytes, b_bytes, id - (kNumConfigs + kNumHalo));

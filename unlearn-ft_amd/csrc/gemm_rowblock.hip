@@ -63,7 +63,7 @@ __device__ unsigned long long pdmk_rb_stamps[1024 * 24];
 #endif
 
 struct RbArgs {
-    unsigned a_bytes, b_bytes, c_bytes, r_bytes, c2_bytes;
+    unsigned a_bytes, b_bytes, c_bytes, r_bytes, c2_bytes, ln_bytes, st_bytes;
     int ngrp;                     // column groups: workgroup (rb, grp) walks n-tiles [grp * per, (grp + 1) * per)
 };
 
@@ -73,7 +73,9 @@ __device__ __forceinline__ i32x4 rsrc_words(const void* p, unsigned bytes) {
 }
 
 // MODE: 0 = bias only, 1 = residual or accumulate (prefetched addend), 2 = PDMK_EPI_GEGLU
-template <int BM, int NJ, int NKA, int BST, int MODE>
+// LNP: LayerNorm of the row block in the prologue (pdmk_gemm_args.ln_gamma) - its own instantiation, so that the plain kernels keep
+// their register allocation (the prologue code in the same body cost them 15 spilled VGPRs)
+template <int BM, int NJ, int NKA, int BST, int MODE, bool LNP = false>
 __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArgs x) {
     typedef Mma<bf16> MM;
     constexpr int BN = 32 * NJ, IM = BM / 64;
@@ -209,6 +211,89 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
     RB_STAMP(3);
 #pragma unroll
     for (int s = PRO; s < DEP; ++s) { issue_b(); mk[s] = issued; }
+
+    // ---- LayerNorm in the prologue (pdmk_gemm_args.ln_gamma; BasicTransformerBlock norm1/2/3 -> the projection that reads it,
+    // blocks.py:705-867): the row block IS in registers - row fr + 16 i of this wave's 16 IM rows spread over the 4 lanes with equal
+    // lane & 15, (lane >> 4) selecting the 8-column chunk of every 32 - so the statistics are one register sweep and two
+    // cross-lane adds per row, and the normalised values replace the fragments in place.  Same arithmetic as ln_fwd_kernel
+    // (norm.hip): mean, variance of the deviations, (x - mean) * rstd * gamma + beta, one rounding to bf16.  Both waves of a row
+    // group (wn = 0 / 1) hold the same rows; wn = 0 of column group 0 writes the statistics and the normalised rows the
+    // backward pass needs (counted buffer stores, out-of-range lanes dropped by the buffer unit).
+    if constexpr (LNP) {
+        const float invK = 1.0f / (float)g.K;
+        const int kq = lane >> 4;
+        const bool writer = wn == 0 && grp == 0;                     // wave-uniform
+        const auto rsrcL = __builtin_amdgcn_make_buffer_rsrc(g.ln_out ? g.ln_out : g.C, (short)0, (int)(g.ln_out ? x.ln_bytes : 0u), 0x00020000);
+        const auto rsrcS = __builtin_amdgcn_make_buffer_rsrc(g.ln_stats ? (void*)g.ln_stats : g.C, (short)0, (int)(g.ln_stats ? x.st_bytes : 0u), 0x00020000);
+        float mean[IM], rstd[IM];
+#pragma unroll
+        for (int i = 0; i < IM; ++i) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKA; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) s1 += (float)af[kt][i][kk][r];          // zero-filled past K
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = s1 * invK;
+            float sq = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKA; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const bool kv = kt * BK + (kk * 4 + kq) * 8 < g.K;                   // a chunk of 8 is inside K or padding
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float d = (float)af[kt][i][kk][r] - mu;
+                        sq += kv ? d * d : 0.f;
+                    }
+                }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            mean[i] = mu;
+            rstd[i] = rsqrtf(sq * invK + g.ln_eps);
+            if (g.ln_stats && writer) {                              // wave-uniform
+                const int m = m0 + wm * (16 * IM) + i * 16 + fr;
+                const unsigned so = (kq == 0 && m < g.M) ? (unsigned)m * 8u : OOB;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{mu, rstd[i]}), rsrcS, (int)so, 0, 0);
+                issued += 1;
+            }
+        }
+#pragma unroll
+        for (int kt = 0; kt < NKA; ++kt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int k0 = kt * BK + (kk * 4 + kq) * 8;
+                const bool kv = k0 < g.K;
+                float gm[8], bt[8];
+                {
+                    const f32x4 g0 = kv ? *reinterpret_cast<const f32x4*>(g.ln_gamma + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 g1 = kv ? *reinterpret_cast<const f32x4*>(g.ln_gamma + k0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 b0 = kv ? *reinterpret_cast<const f32x4*>(g.ln_beta + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 b1 = kv ? *reinterpret_cast<const f32x4*>(g.ln_beta + k0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { gm[r] = g0[r]; gm[4 + r] = g1[r]; bt[r] = b0[r]; bt[4 + r] = b1[r]; }
+                }
+#pragma unroll
+                for (int i = 0; i < IM; ++i) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o[r] = (bf16)(((float)af[kt][i][kk][r] - mean[i]) * rstd[i] * gm[r] + bt[r]);
+                    af[kt][i][kk] = o;                               // (padding chunks: gamma = beta = 0 -> stays 0)
+                    if (g.ln_out && writer) {                        // wave-uniform
+                        const int m = m0 + wm * (16 * IM) + i * 16 + fr;
+                        const unsigned oo = (kv && m < g.M) ? ((unsigned)m * (unsigned)g.ld_ln_out + (unsigned)k0) * 2u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcL, (int)oo, 0, 0);
+                        issued += 1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);                   // one slot's gamma / beta (16 registers) at a time: hoisting all
+            }                                                        // 2 NKA slots' loads to the top spills
+    }
 
     // ---- per-lane epilogue geometry (row-contiguous read-back of the wave's 16 x WCOLS staging image)
     const int mrow0 = m0 + wm * (16 * IM);
@@ -502,7 +587,8 @@ int pdmk_gemm_rowblock_name(int id, char* buf, int n) {
 }
 
 // returns 1 if the shape / epilogue is not handled here (the caller falls back), 0 on launch, < 0 on a launch error
-int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id) {
+// dry: answer only (0 = this candidate takes the problem), nothing is launched
+int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_bytes, long b_bytes, int id, bool dry) {
     using namespace pdmk_rb;
     if (id < 0 || id >= kNumRb || !rb_enabled()) return 1;
     const RbCfg c = kRb[id];
@@ -517,25 +603,35 @@ int pdmk_gemm_rowblock_launch(const pdmk_gemm_args& g, hipStream_t st, long a_by
     const bool geglu = g.epilogue == PDMK_EPI_GEGLU;
     if (g.epilogue != PDMK_EPI_NONE && !geglu) return 1;
     if (g.colstat) return 1;                             // GroupNorm statistics epilogue: ring / halo kernels only
+    if (g.ln_gamma && (!g.ln_beta || ((uintptr_t)g.ln_gamma & 15) || ((uintptr_t)g.ln_beta & 15) || (g.ln_out && (g.ld_ln_out % 8)) ||
+                       ((uintptr_t)g.ln_out & 15) || ((uintptr_t)g.ln_stats & 7)))
+        return 1;
     if (geglu && ((g.N % 16) || g.R || g.accumulate || (g.C2 && (g.ldc2 % 8)))) return 1;
     const long c_bytes = ((long)(g.M - 1) * g.ldc + (geglu ? g.N / 2 : g.N)) * 2;
     const long r_bytes = g.R ? ((long)(g.M - 1) * g.ldr + g.N) * 2 : 0;
     const long c2_bytes = g.C2 ? ((long)(g.M - 1) * g.ldc2 + g.N) * 2 : 0;
-    if (c_bytes >= (1L << 31) || r_bytes >= (1L << 31) || c2_bytes >= (1L << 31)) return 1;
+    const long ln_bytes = (g.ln_gamma && g.ln_out) ? ((long)(g.M - 1) * g.ld_ln_out + g.K) * 2 : 0;
+    const long st_bytes = (g.ln_gamma && g.ln_stats) ? (long)g.M * 8 : 0;
+    if (c_bytes >= (1L << 31) || r_bytes >= (1L << 31) || c2_bytes >= (1L << 31) || ln_bytes >= (1L << 31)) return 1;
     // column groups: fill the 256 CUs with (row blocks x groups) workgroups, at least one n-tile per group
     int ngrp = grp_override() > 0 ? grp_override() : (256 + ntm / 2) / ntm;
     if (ngrp < 1) ngrp = 1;
     if (ngrp > ntn) ngrp = ntn;
     const int per = (ntn + ngrp - 1) / ngrp;
     ngrp = (ntn + per - 1) / per;                                    // no empty groups
-    RbArgs x{(unsigned)a_bytes, (unsigned)b_bytes, (unsigned)c_bytes, (unsigned)r_bytes, (unsigned)c2_bytes, ngrp};
+    RbArgs x{(unsigned)a_bytes, (unsigned)b_bytes, (unsigned)c_bytes, (unsigned)r_bytes, (unsigned)c2_bytes, (unsigned)ln_bytes,
+             (unsigned)st_bytes, ngrp};
     dim3 grid(ntm * ngrp);
+    if (dry) return 0;
     const int mode = geglu ? 2 : ((g.R || g.accumulate == 1) ? 1 : 0);
 #define PDMK_RB_GO(BMv, NJv, NKv, STv)                                                                                  \
-    switch (mode) {                                                                                                     \
+    switch (mode + (g.ln_gamma ? 3 : 0)) {                                                                              \
         case 0: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 0>), grid, dim3(NT), 0, st, g, x); break;       \
         case 1: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 1>), grid, dim3(NT), 0, st, g, x); break;       \
-        default: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 2>), grid, dim3(NT), 0, st, g, x); break;      \
+        case 2: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 2>), grid, dim3(NT), 0, st, g, x); break;       \
+        case 3: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 0, true>), grid, dim3(NT), 0, st, g, x); break; \
+        case 5: hipLaunchKernelGGL((rowblock_kernel<BMv, NJv, NKv, STv, 2, true>), grid, dim3(NT), 0, st, g, x); break; \
+        default: return 1;                                                                                              \
     }
     switch (id) {
         case 0: PDMK_RB_GO(128, 5, 5, 5) break;

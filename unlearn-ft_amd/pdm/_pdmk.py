@@ -42,7 +42,8 @@ class GemmArgs(C.Structure):
                 ("conv_b", i32), ("conv_hi", i32), ("conv_wi", i32), ("conv_ci", i32), ("conv_ho", i32),
                 ("conv_wo", i32), ("conv_mode", i32), ("conv_ld", i32),
                 ("dtype", i32), ("out_f32", i32), ("accumulate", i32), ("splitk", i32), ("alpha", f32), ("ldrv", i32),
-                ("epilogue", i32), ("ldc2", i32), ("C2", vp), ("colstat", vp), ("cs_ld", i32), ("cs_col0", i32)]
+                ("epilogue", i32), ("ldc2", i32), ("C2", vp), ("colstat", vp), ("cs_ld", i32), ("cs_col0", i32),
+                ("ln_gamma", vp), ("ln_beta", vp), ("ln_stats", vp), ("ln_out", vp), ("ld_ln_out", i32), ("ln_eps", f32)]
 
 
 _SIGS = {
@@ -50,6 +51,7 @@ _SIGS = {
     "pdmk_gemm": ([C.POINTER(GemmArgs), vp], i32),
     "pdmk_gemm_group": ([C.POINTER(GemmArgs), i32, vp, C.POINTER(i32)], i32),
     "pdmk_gemm_plan": ([C.POINTER(GemmArgs), vp, C.POINTER(i32)], i32),
+    "pdmk_gemm_ln_supported": ([C.POINTER(GemmArgs)], i32),
     "pdmk_conv_up2_supported": ([i32, i32, i32, i32, i32, i32], i32),
     "pdmk_up2_pack_weights": ([vp, vp, vp, i32, i32, i32, vp], i32),
     "pdmk_up2_combine_wgrad": ([vp, vp, i32, i32, vp], i32),
@@ -232,7 +234,8 @@ def gemm_group(recs):
         g0 = recs[0].g
         kind = ("bf16" if g0.dtype == BF16 else "f32", g0.a_mode, g0.b_mode, _lib.pdmk_gemm_last_candidate(), int(got.value))
         flops = sum(2.0 * (r.macs if r.macs is not None else r.g.M * r.g.N * r.g.K) for r in recs)
-        PROFILE.append((kind, flops, e0, e1, [(r.g.M, r.g.N, r.g.K, int(r.g.splitk)) for r in recs]))
+        PROFILE.append((kind, flops, e0, e1, [(r.g.M, r.g.N, r.g.K, int(r.g.splitk), int(bool(r.g.R) or r.g.accumulate == 1))
+                                               for r in recs]))
     return int(got.value)
 
 
@@ -273,8 +276,9 @@ _GROUP_FNS = {}     # kind -> fn(list of Rec): grouped forms of the non-GEMM for
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per_b=0, R=None, ldr=0,
          a_mode=A_ROWK, b_mode=B_ROWK, conv=None, dtype=None, out_f32=False, accumulate=False, splitk=1, alpha=1.0,
-         macs=None, colsum_out=None, ldrv=0, epilogue=EPI_NONE, C2=None, ldc2=0, colstat=None):
+         macs=None, colsum_out=None, ldrv=0, epilogue=EPI_NONE, C2=None, ldc2=0, colstat=None, ln=None):
     # accumulate: False / True / 2 (= split-K slabs, see pdmk.h)
+    # ln = (gamma, beta, stats or None, out or None, eps): LayerNorm(A) in the GEMM's prologue (pdmk_gemm_args.ln_gamma)
     """conv = (b, hi, wi, ci, ho, wo, mode, ld) or None.  macs: logical (un-padded) multiply-accumulates, profiling only."""
     g = GemmArgs()
     g.colsum_out = _p(colsum_out)
@@ -291,12 +295,38 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, *, bias=None, rowvec=None, rows_per
     g.epilogue, g.C2, g.ldc2 = int(epilogue), _p(C2), int(ldc2)
     if colstat is not None:          # (accumulator [B, 4, cs_ld] int64 limbs, first accumulator column of this output)
         g.colstat, g.cs_ld, g.cs_col0 = _p(colstat[0]), colstat[0].shape[2], int(colstat[1])
-    shape = (M, N, K, int(splitk))
+    _set_ln(g, ln)
+    shape = (M, N, K, int(splitk), int(R is not None or int(accumulate) == 1))     # last: the epilogue also READS an [M, N] tensor
     if RECORD is not None:
         RECORD.append(Rec("gemm", lambda: _launch_gemm(g, macs, shape), g=g, macs=macs,
-                          keep=(A, B, Cout, bias, rowvec, R, colsum_out, C2, colstat)))
+                          keep=(A, B, Cout, bias, rowvec, R, colsum_out, C2, colstat, ln)))
         return
     _launch_gemm(g, macs, shape)
+
+
+def _set_ln(g, ln):
+    if ln is None:
+        return
+    gamma, beta, stats, out, eps = ln
+    g.ln_gamma, g.ln_beta, g.ln_stats, g.ln_out = _p(gamma), _p(beta), _p(stats), _p(out)
+    g.ld_ln_out, g.ln_eps = (0 if out is None else out.stride(0)), float(eps)
+
+
+def gemm_ln_supported(A, B, M, N, K, lda, ldb, *, geglu=False, residual=False, bias=False):
+    """Would pdmk_gemm take this Linear with the LayerNorm of its input fused into the prologue (one launch)?  Shape question only:
+    the pointers are placeholders."""
+    g = GemmArgs()
+    g.A, g.B, g.C = _p(A), _p(B), _p(A)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, (N // 2 if geglu else N)
+    g.a_mode, g.b_mode, g.dtype, g.splitk, g.alpha = A_ROWK, B_ROWK, dt(A), 1, 1.0
+    g.epilogue = EPI_GEGLU if geglu else EPI_NONE
+    if residual:
+        g.R, g.ldr = _p(A), N
+    if bias or geglu:
+        g.bias = _p(B)
+    g.ln_gamma = g.ln_beta = _p(B)
+    g.ln_eps = 1e-5
+    return bool(_lib.pdmk_gemm_ln_supported(C.byref(g)))
 
 
 def _ws_bytes(n):
@@ -553,36 +583,40 @@ _WG_MINK = int(os.environ.get("PDMK_WG_MINK", "32"))           # and the fewest 
 
 
 def wgrad_group(items, queue, target_wgs=None):
-    """The Linear weight gradients of one transformer block (blocks.py:705-867 backward: to_q/k/v, to_out, ff.net.0.proj,
-    ff.net.2, proj_in, proj_out reached from accelerator.backward, trainer.py:2782) as grouped launches (pdmk_gemm_group): every
-    item reduces over the SAME K pixel rows into a small [M, N] output, so one problem alone fills the 256 CUs only by cutting its
-    reduction into 16-32 splits (16 K-steps each behind a cold prologue, 16-32 slabs to add); together the problems have the tiles,
-    so they share ONE split factor chosen for the group (>= 32 K-steps per split) and one launch.
-    items: (dy, x, dW, M, N, K, lda, ldb, colsum_out, macs) with dW fp32 [M, N] contiguous; queue: the SlabQueue that adds the
-    slabs of split problems later.  Problems the grouped kernels do not take go out one by one (same results either way)."""
-    items = list(items)
+    """The weight gradients of one block (blocks.py:705-867 backward: to_q/k/v, to_out, ff.net.0.proj, ff.net.2, proj_in, proj_out
+    of a transformer block; blocks.py:308-381 backward: conv1 / conv2 of a ResBlock; reached from accelerator.backward,
+    trainer.py:2782) as grouped launches (pdmk_gemm_group): every item reduces over the SAME K pixel rows into a small [M, N]
+    output, so one problem alone fills the 256 CUs only by cutting its reduction into 16-32 splits (16 K-steps each behind a cold
+    prologue, 16-32 slabs to add); together the problems have the tiles, so they share ONE split factor chosen for the group
+    (>= _WG_MINK K-steps per split) and one launch.
+    items: (dy, x, dW, M, N, K, lda, ldb, colsum_out, macs[, b_mode, conv]) with dW fp32 [M, N] contiguous; Linear items
+    (b_mode B_COLK) store the slabs of a split reduction for `queue` (a SlabQueue) to add later, 3x3 conv items (B_COLK_CONV) add
+    their splits with atomics as k.wgrad does.  Problems the grouped kernels do not take go out one by one (same results)."""
+    items = [tuple(it) + (B_COLK, None) if len(it) == 10 else tuple(it) for it in items]
     while items:
-        K = items[0][5]
-        same = [it for it in items if it[5] == K][:GROUP_MAX]
+        K, bm = items[0][5], items[0][10]
+        same = [it for it in items if it[5] == K and it[10] == bm][:GROUP_MAX]
         items = [it for it in items if not any(it is s_ for s_ in same)]
+        conv_g = bm == B_COLK_CONV
         tiles = sum(((it[3] + 127) // 128) * ((it[4] + 127) // 128) for it in same)
         nk = max(1, K // 64)
         sk = max(1, min((target_wgs or _WG_TARGET) // max(tiles, 1), nk // _WG_MINK, 64))
-        if len(same) == 1 or queue is None:
-            for dy, x, dW, M, N, K_, lda, ldb, cs, macs in same:
-                wgrad(dy, x, dW, M, N, K_, lda, ldb, colsum_out=cs, macs=macs, queue=queue)
+        if len(same) == 1 or (queue is None and not conv_g):
+            for dy, x, dW, M, N, K_, lda, ldb, cs, macs, bm_, conv in same:
+                wgrad(dy, x, dW, M, N, K_, lda, ldb, b_mode=bm_, conv=conv, colsum_out=cs, macs=macs, queue=None if conv_g else queue)
             continue
         with Recorder() as r:
             slabs = []
-            for dy, x, dW, M, N, K_, lda, ldb, cs, macs in same:
-                if sk > 1 and (M * N) % 4 == 0 and dW.is_contiguous():
+            for dy, x, dW, M, N, K_, lda, ldb, cs, macs, bm_, conv in same:
+                if not conv_g and sk > 1 and (M * N) % 4 == 0 and dW.is_contiguous():
                     ws = torch.empty(sk * M * N, device=dy.device, dtype=torch.float32)
-                    gemm(dy, x, ws, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=B_COLK, out_f32=True, splitk=sk, accumulate=2,
+                    gemm(dy, x, ws, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=bm_, out_f32=True, splitk=sk, accumulate=2,
                          dtype=dt(x), macs=macs, colsum_out=cs)
                     slabs.append((ws, dW, M * N, sk))
-                else:
-                    gemm(dy, x, dW, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=B_COLK, out_f32=True, splitk=1, accumulate=True,
-                         dtype=dt(x), macs=macs, colsum_out=cs)
+                else:       # unsplit: added into the gradient in the epilogue; conv splits: fp32 atomics into it
+                    ska = sk if conv_g else 1
+                    gemm(dy, x, dW, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=bm_, conv=conv, out_f32=True, splitk=ska,
+                         accumulate=(ska == 1), dtype=dt(x), macs=macs, colsum_out=cs)
         gemm_group(r.recs)
         for ws, dW, n, nslab in slabs:
             if queue.full():
@@ -721,7 +755,8 @@ def _launch_gemm_geglu(g, macs):
         e0.record()
     rc = _lib.pdmk_gemm(C.byref(g), _st())
     if rc == -2:
-        _GEGLU_REFUSED.add((g.M, g.N, g.K))
+        if not g.ln_gamma:
+            _GEGLU_REFUSED.add((g.M, g.N, g.K))
         return False
     _chk(rc, "pdmk_gemm[geglu]")
     if PROFILE is not None:
@@ -731,7 +766,7 @@ def _launch_gemm_geglu(g, macs):
     return True
 
 
-def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
+def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None, ln=None):
     """gl[M, N/2] = GEGLU(A @ B^T + bias) in the GEMM's epilogue, (hidden, gate) columns interleaved in blocks of 8; f (or
     None) receives the [M, N] pre-activation for the backward.  Returns False when the library has no fused kernel for
     the shape (status -2) - the caller then runs the projection and pdmk_geglu_fwd(layout=1) as two passes.
@@ -746,6 +781,7 @@ def gemm_geglu(A, B, gl, f, M, N, K, lda, ldb, *, bias=None, macs=None):
     g.a_mode, g.b_mode, g.dtype = A_ROWK, B_ROWK, dt(A)
     g.splitk, g.alpha = 1, 1.0
     g.epilogue, g.C2, g.ldc2 = EPI_GEGLU, _p(f), 0 if f is None else f.stride(0)
+    _set_ln(g, ln)
     if RECORD is not None:
         def run():
             if not _launch_gemm_geglu(g, macs):

@@ -80,6 +80,9 @@ class UNetEngine:
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
         self.wgrad_stream = None          # the dedicated "wgrad" role stream, created on first use
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
+        # LayerNorm in the prologue of the Linear that reads it (linear(ln=...)): 0 = never, 1 = where it measured as a gain (every
+        # K <= 320 pair; K <= 640 without the GEGLU epilogue), 2 = wherever the library takes the pair
+        self.fuse_ln = int(os.environ.get("PDMK_FUSE_LN", "1"))
         self.fuse_geglu_bwd = os.environ.get("PDMK_FUSE_GEGLU_BWD", "1") != "0"   # same for the backward (ff.net.2's input gradient)
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -100,6 +103,8 @@ class UNetEngine:
         # Linear weight gradients of a transformer block: collected during the block's backward and issued as grouped launches at
         # its start marker (k.wgrad_group; PDMK_WGRAD_GROUP=0: one launch per weight, as they are produced)
         self.group_wgrad = os.environ.get("PDMK_WGRAD_GROUP", "1") != "0" and dtype == torch.bfloat16 and self.slabs is not None
+        # ... and conv1 / conv2 (+ the 1x1 shortcut) of a ResBlock the same way (PDMK_WGRAD_GROUP_CONV=0: as they are produced)
+        self.group_conv_wgrad = self.group_wgrad and os.environ.get("PDMK_WGRAD_GROUP_CONV", "1") != "0"
         self._wg_items = None
         self._cs_arena, self._cs_off, self._cs_need, self._cs_old = None, 0, 0, []
         self._cs_views, self._cs_cats = {}, {}
@@ -189,8 +194,12 @@ class UNetEngine:
         return max(1, min(512 // max(tiles, 1), nk // 16, 64))   # >= 16 K-steps per split (measured sweet spot)
 
     # ------------------------------------------------------------------ ops
-    def linear(self, x, key, bias=None, residual=None, out_f32=False, out=None, geglu=False, cs=None):
-        """out: optional [M, N] view (any row stride) to write into instead of a fresh tensor (concat buffers).
+    def linear(self, x, key, bias=None, residual=None, out_f32=False, out=None, geglu=False, cs=None, ln=None):
+        """ln: key prefix of a LayerNorm whose output this Linear reads (BasicTransformerBlock norm1/2/3, blocks.py:705-867): x is
+        the UN-normalised tensor; where the library takes the pair as one launch (pdmk_gemm_args.ln_gamma: the row-block kernel
+        normalises the row block in its registers) the LayerNorm has no pass of its own - the normalised rows and (mean, rstd) are
+        written only when a backward pass will read them - else the LayerNorm runs first, as a launch of its own.
+        out: optional [M, N] view (any row stride) to write into instead of a fresh tensor (concat buffers).
         geglu: the projection is GEGLU's (blocks.py:44-59; weight rows packed (hidden, gate)-interleaved, params.py): returns
         hidden * gelu(gate) [M, N/2], computed in the GEMM's epilogue where the library has the fused kernel (bf16 ring
         kernels; the pre-activation is then only written when a backward pass will need it), else as a second pass."""
@@ -205,22 +214,48 @@ class UNetEngine:
         # time-embedding MLP / batched time_emb_proj: M = batch rows -> weight-streaming kernels (skinny operand in LDS)
         skinny = M <= 16 and residual is None and (8 if M <= 8 else 16) * Kp * 4 + 512 <= 65536
         skinny_dgrad = skinny and (8 if M <= 8 else 16) * Np * 4 + 512 <= 65536
+        a_t, ln_args, ln_src = x.t, None, None             # forward A operand; the LayerNorm prologue of the GEMM, its input Act
+        if ln is not None:
+            take = (self.fuse_ln and self.dtype == torch.bfloat16 and not skinny and residual is None and out is None and
+                    not out_f32 and cs is None and (self.fuse_ln >= 2 or Kp <= 320 or not geglu) and
+                    k.gemm_ln_supported(x.t, P.wv(key + ".weight"), M, Np, Kp, _ld(x.t), Kp, geglu=geglu, bias=bool(bias)))
+            if not take:
+                x = self.layernorm(x, ln)
+                a_t = x.t
+            else:
+                ln_src = x
+                st_ = torch.empty((M, 2), device=self.dev, dtype=torch.float32) if self.train else None
+                lno = self._empty(M, Kp) if self.train else None
+                ln_args = (P.p(ln + ".weight"), P.p(ln + ".bias"), st_, lno, 1e-5)
+                x = Act(lno)                                 # what the backward pass sees as this Linear's input
+                if self.train:
+                    lnw, src = P.p(ln + ".weight"), ln_src
+
+                    def lnbwd():                             # runs AFTER this Linear's backward (appended before it)
+                        dx, acc_, add = self._grad_into(src, M, Kp, absorb=True)
+                        k.layernorm_bwd(src.t, x.g, dx, lnw, st_, P.g(ln + ".weight"), P.g(ln + ".bias"), M, Kp, _ld(src.t),
+                                        _ld(x.g), _ld(dx), acc_, queue=self.partials, add=add)
+                    self.tape.append(lnbwd)
         gl = None
         acc, acc_ok = None, False       # GroupNorm statistics out of this GEMM's epilogue (cs): the accumulator slice, and whether it was fed
         if geglu:
             assert residual is None and out is None and not out_f32
             gl = self._empty(M, Np // 2)
             fused = (self.fuse_geglu and not skinny and self.dtype == torch.bfloat16 and
-                     k.splitk_plan(x.t, P.wv(key + ".weight"), M, Np, Kp, _ld(x.t), Kp) == 1)
+                     (ln_args is not None or k.splitk_plan(a_t, P.wv(key + ".weight"), M, Np, Kp, _ld(a_t), Kp) == 1))
             if fused:
                 if not self.train:
                     y = None                    # inference (teacher): the [M, N] pre-activation never reaches memory
-                fused = k.gemm_geglu(x.t, P.wv(key + ".weight"), gl, y, M, Np, Kp, _ld(x.t), Kp,
-                                     bias=P.p(bias) if bias else None, macs=M * e.logical[0] * e.logical[1])
+                fused = k.gemm_geglu(a_t, P.wv(key + ".weight"), gl, y, M, Np, Kp, _ld(a_t), Kp,
+                                     bias=P.p(bias) if bias else None, macs=M * e.logical[0] * e.logical[1], ln=ln_args)
+                assert fused or ln_args is None, "pdmk_gemm_ln_supported said yes"
                 if not fused and y is None:
                     y = self._empty(M, Np)
         if geglu and fused:
             pass
+        elif ln_args is not None:      # LayerNorm prologue: one kernel family, no plan to make
+            k.gemm(a_t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(a_t), Kp, _ld(y), bias=P.p(bias) if bias else None,
+                   macs=M * e.logical[0] * e.logical[1], ln=ln_args)
         elif skinny:
             k.skinny_gemm(x.t, P.wv(key + ".weight"), y, M, Np, Kp, _ld(x.t), Kp, _ld(y), bias=P.p(bias) if bias else None)
         else:
@@ -339,11 +374,17 @@ class UNetEngine:
                 dy = out.g
                 ldy = _ld(dy)
                 xt = x.t
-                self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, b_mode=k.B_COLK_CONV,
-                                            conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), macs=lmacs,
-                                            colsum_out=P.g(bias),       # bias gradient fused into the weight gradient
-                                            queue=None if (self.wgrad_async or not self.conv_slabs) else self.slabs),
-                            dy, xt)
+                collect = (self._wg_items is not None and self.group_conv_wgrad and not self.wgrad_async and not self.conv_slabs
+                           and mode == 0)
+                if collect:      # conv1 / conv2 of a ResBlock: one grouped launch at the block's start marker
+                    self._wg_items.append((dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, P.g(bias), lmacs, k.B_COLK_CONV,
+                                           (B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt))))
+                else:
+                    self._wgrad(lambda: k.wgrad(dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, b_mode=k.B_COLK_CONV,
+                                                conv=(B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt)), macs=lmacs,
+                                                colsum_out=P.g(bias),       # bias gradient fused into the weight gradient
+                                                queue=None if (self.wgrad_async or not self.conv_slabs) else self.slabs),
+                                dy, xt)
                 if x.rg:
                     if mode == 2:
                         tmp = self._empty(M, Cip)
@@ -370,7 +411,7 @@ class UNetEngine:
                     k.colsum(dy, dtp, hw, Cop, ldy, accumulate=True, nbatch=B, ldo=_ld(rowvec.g))
                 if residual is not None:
                     self._wgrad_fence()
-                    self._give(residual, dy)
+                    self._give(residual, dy, park=collect)
             self.tape.append(bwd)
         return out, Ho, Wo
 
@@ -670,11 +711,15 @@ class UNetEngine:
         G = self.cfg.norm_num_groups
         p = r.name
         self._mark(p + ".norm1.weight")
+        if self.train and self.group_conv_wgrad:
+            self.tape.append(self._wg_flush)
         n1 = self.groupnorm(x, p + ".norm1", B, H * W, G, r.cin // G, 1e-5, True)
         h1, _, _ = self.conv3(n1, p + ".conv1", B, H, W, 0, p + ".conv1.bias", rowvec=st, rv_cols=self.temb_lay[p][:2], cs=True)
         n2 = self.groupnorm(h1, p + ".norm2", B, H * W, r.groups2(G), r.cout // G, 1e-5, True)
         res = x if r.cin == r.cout else self.linear(x, p + ".conv_shortcut", bias=p + ".conv_shortcut.bias")
         y, _, _ = self.conv3(n2, p + ".conv2", B, H, W, 0, p + ".conv2.bias", residual=res, out=out, cs=cs)
+        if self.train and self.group_conv_wgrad:
+            self.tape.append(self._wg_open)
         return y
 
     def transformer(self, x, a, ehs, B, H, W, T, out=None, cs=True):
@@ -687,19 +732,16 @@ class UNetEngine:
             self.tape.append(self._wg_flush)       # runs at the end of the block's backward, before the mark above
         n = self.groupnorm(x, p + ".norm", B, N, G, c // G, 1e-6, False)
         h = self.linear(n, p + ".proj_in", bias=p + ".proj_in.bias")
-        l1 = self.layernorm(h, t + ".norm1")
-        qkv = self.linear(l1, t + ".attn1.to_qkv")
+        qkv = self.linear(h, t + ".attn1.to_qkv", ln=t + ".norm1")
         o = self.attention(qkv.t[:, :d1], qkv.t[:, d1:2 * d1], qkv.t[:, 2 * d1:3 * d1], B, a.h1(), N, N, qkv, qkv,
                            (0, d1), ((d1, 2 * d1), (2 * d1, 3 * d1)), tag=t + ".attn1")
         h = self.linear(o, t + ".attn1.to_out.0", bias=t + ".attn1.to_out.0.bias", residual=h)
-        l2 = self.layernorm(h, t + ".norm2")
-        q = self.linear(l2, t + ".attn2.to_q")
+        q = self.linear(h, t + ".attn2.to_q", ln=t + ".norm2")
         kv, ko = ehs, self.kv_lay[p][0]      # `ehs` = the batched K/V projection of all transformers; this one's columns
         o = self.attention(q.t[:, :d2], kv.t[:, ko:ko + d2], kv.t[:, ko + d2:ko + 2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
                            ((ko, ko + d2), (ko + d2, ko + 2 * d2)), tag=t + ".attn2")
         h = self.linear(o, t + ".attn2.to_out.0", bias=t + ".attn2.to_out.0.bias", residual=h)
-        l3 = self.layernorm(h, t + ".norm3")
-        gl = self.linear(l3, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True)
+        gl = self.linear(h, t + ".ff.net.0.proj", bias=t + ".ff.net.0.proj.bias", geglu=True, ln=t + ".norm3")
         h = self.linear(gl, t + ".ff.net.2", bias=t + ".ff.net.2.bias", residual=h)
         y = self.linear(h, p + ".proj_out", bias=p + ".proj_out.bias", residual=x, out=out, cs=(B, N) if cs else None)
         if self.train and self.group_wgrad:
