@@ -29,10 +29,11 @@ def dev():
 
 @pytest.fixture(autouse=True)
 def _gpu_test_hygiene(request):
-    """Between GPU tests: collect garbage and drain the device.  Several tests build hipGraphs whose owners sit in reference
-    cycles; left to the cyclic collector they would be destroyed at an arbitrary point of a LATER test - e.g. between two
-    graph replays on different streams (one full-suite run ended in a host segfault inside hipGraphLaunch that no test
-    reproduces on its own).  Destroying them here, with the device idle, makes the order deterministic."""
+    """Between GPU tests: collect garbage and drain the device - housekeeping only.  Several tests build hipGraphs whose owners
+    sit in reference cycles; collecting them here, with the device idle, keeps graph destruction out of the middle of a later
+    test's replays and the suite's memory footprint flat.  (Round 2's host segfault inside hipGraphLaunch, which this fixture was
+    first written against, is root-caused and removed by construction - an unbounded walk over `parallel_streams_` in
+    hip::Graph::UpdateStreams that only multi-branch graphs enter; every captured graph is single-stream now, DESIGN.md 2.1.)"""
     gpu = request.node.get_closest_marker("gpu") is not None
     if gpu:
         import gc

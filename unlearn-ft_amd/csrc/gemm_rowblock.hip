@@ -152,6 +152,18 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
     }
     issued += NA * NKA;
     const int markA = issued;
+    // LayerNorm prologue: gamma | beta (KP floats each, zero past K) requested NOW, one or two floats per thread, so that their
+    // round trip hides behind the A image's; they go to LDS once the A image is dead (one ds_read per use instead of a dependent
+    // global load per K-chunk: ten serialised L2 round trips made the fused launch no faster than LayerNorm + GEMM)
+    constexpr int KP = NKA * BK, LNW = (2 * KP + NT - 1) / NT;
+    float lnv[LNW];
+    if constexpr (LNP) {
+#pragma unroll
+        for (int j = 0; j < LNW; ++j) {
+            const int idx = tid + NT * j, kk_ = idx < KP ? idx : idx - KP;
+            lnv[j] = (idx < 2 * KP && kk_ < g.K) ? (idx < KP ? g.ln_gamma[kk_] : g.ln_beta[kk_]) : 0.f;
+        }
+    }
 
     // ---- weight stream: stage qi = (n-tile ti, K-step ki) into ring slot si.  mk[] = `issued` right after the issue of
     // the (at most BST-1) stages in flight, oldest first: a shift register with constant indices only (a slot-indexed
@@ -220,6 +232,11 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
     // group (wn = 0 / 1) hold the same rows; wn = 0 of column group 0 writes the statistics and the normalised rows the
     // backward pass needs (counted buffer stores, out-of-range lanes dropped by the buffer unit).
     if constexpr (LNP) {
+        float* const lnp = reinterpret_cast<float*>(smem + RING);     // the waves' staging area: unused until the first epilogue
+        static_assert(2 * KP * 4 <= 8 * STG_WAVE, "gamma | beta fit the staging area");
+#pragma unroll
+        for (int j = 0; j < LNW; ++j)
+            if (tid + NT * j < 2 * KP) lnp[tid + NT * j] = lnv[j];
         const float invK = 1.0f / (float)g.K;
         const int kq = lane >> 4;
         const bool writer = wn == 0 && grp == 0;                     // wave-uniform
@@ -263,6 +280,8 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
                 issued += 1;
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // gamma | beta are in LDS for every wave
 #pragma unroll
         for (int kt = 0; kt < NKA; ++kt)
 #pragma unroll
@@ -271,10 +290,8 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
                 const bool kv = k0 < g.K;
                 float gm[8], bt[8];
                 {
-                    const f32x4 g0 = kv ? *reinterpret_cast<const f32x4*>(g.ln_gamma + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    const f32x4 g1 = kv ? *reinterpret_cast<const f32x4*>(g.ln_gamma + k0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    const f32x4 b0 = kv ? *reinterpret_cast<const f32x4*>(g.ln_beta + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    const f32x4 b1 = kv ? *reinterpret_cast<const f32x4*>(g.ln_beta + k0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(lnp + k0), g1 = *reinterpret_cast<const f32x4*>(lnp + k0 + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(lnp + KP + k0), b1 = *reinterpret_cast<const f32x4*>(lnp + KP + k0 + 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { gm[r] = g0[r]; gm[4 + r] = g1[r]; bt[r] = b0[r]; bt[4 + r] = b1[r]; }
                 }
@@ -291,8 +308,10 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
                         issued += 1;
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);                   // one slot's gamma / beta (16 registers) at a time: hoisting all
-            }                                                        // 2 NKA slots' loads to the top spills
+                if (kk) __builtin_amdgcn_sched_barrier(0);           // two slots' gamma / beta (32 registers) in flight at a time:
+            }                                                        // hoisting all 2 NKA slots' reads to the top spills
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                // the staging area is the waves' own again (first epilogue)
     }
 
     // ---- per-lane epilogue geometry (row-contiguous read-back of the wave's 16 x WCOLS staging image)

@@ -321,7 +321,15 @@ class BilevelStepper:
         return noisy, target
 
     def _ehs2d(self, e):
-        return e.to(self.dev).to(self.student.dtype).reshape(e.shape[0] * e.shape[1], e.shape[2]).contiguous()
+        """[B, T, D] prompt embeddings (fp32 in the reference's batch schema, data_utils.py:286-312) -> [B * T, D] rows in the
+        compute dtype; the cast is pdmk_cast_permute, so a replayed step holds no torch arithmetic kernel for it."""
+        e = e.to(self.dev)
+        rows, cols = e.shape[0] * e.shape[1], e.shape[2]
+        if e.dtype == torch.float32 and self.student.dtype != torch.float32 and e.is_contiguous():
+            out = torch.empty((rows, cols), device=self.dev, dtype=self.student.dtype)
+            k.cast_permute(e, out, rows * cols, 1, 1, 0)
+            return out
+        return e.to(self.student.dtype).reshape(rows, cols).contiguous()
 
     def _block_loss(self, acts_s, acts_t, B, weight, uncond_half=False, seed=True):
         """(1/9) sum_k mse(student_k, teacher_k) (trainer.py:2475-2481) and its gradient seeds; uncond_half: the upper step
@@ -572,7 +580,7 @@ class GraphedBilevel:
         self.force_segments = False          # tests: cut the backward into segments on a single rank without streamed AdamW
         # AdamW of every finished share of the arena runs beside the rest of the backward (valid without gradient-norm
         # clipping, which needs all gradients first; the shipped configs do not clip: trainer.py:2784-2786)
-        self.stream_opt = stream_opt
+        self.stream_opt = stream_opt and os.environ.get("PDMK_STREAM_OPT", "1") != "0"     # (0: A/B switch - AdamW after the backward)
         self.opt_stream = k.role_stream(dev, "opt")
         self.cap_stream = k.role_stream(dev, "capture")
         self.closed = False
