@@ -229,8 +229,9 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
     // lane & 15, (lane >> 4) selecting the 8-column chunk of every 32 - so the statistics are one register sweep and two
     // cross-lane adds per row, and the normalised values replace the fragments in place.  Same arithmetic as ln_fwd_kernel
     // (norm.hip): mean, variance of the deviations, (x - mean) * rstd * gamma + beta, one rounding to bf16.  Both waves of a row
-    // group (wn = 0 / 1) hold the same rows; wn = 0 of column group 0 writes the statistics and the normalised rows the
-    // backward pass needs (counted buffer stores, out-of-range lanes dropped by the buffer unit).
+    // group (wn = 0 / 1) hold the same rows; in column group 0 wn = 0 writes the statistics and each of the two the half of the
+    // normalised rows' 32-column chunks with kk == wn - what the backward pass needs (counted buffer stores, out-of-range lanes
+    // dropped by the buffer unit).
     if constexpr (LNP) {
         float* const lnp = reinterpret_cast<float*>(smem + RING);     // the waves' staging area: unused until the first epilogue
         static_assert(2 * KP * 4 <= 8 * STG_WAVE, "gamma | beta fit the staging area");
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(NT, 2) void rowblock_kernel(pdmk_gemm_args g, RbArg
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (bf16)(((float)af[kt][i][kk][r] - mean[i]) * rstd[i] * gm[r] + bt[r]);
                     af[kt][i][kk] = o;                               // (padding chunks: gamma = beta = 0 -> stays 0)
-                    if (g.ln_out && writer) {                        // wave-uniform
+                    if (g.ln_out && grp == 0 && kk == wn) {          // wave-uniform: the two waves of a row group share the stores
                         const int m = m0 + wm * (16 * IM) + i * 16 + fr;
                         const unsigned oo = (kv && m < g.M) ? ((unsigned)m * (unsigned)g.ld_ln_out + (unsigned)k0) * 2u : OOB;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rsrcL, (int)oo, 0, 0);

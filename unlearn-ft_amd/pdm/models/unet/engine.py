@@ -80,8 +80,9 @@ class UNetEngine:
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
         self.wgrad_stream = None          # the dedicated "wgrad" role stream, created on first use
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
-        # LayerNorm in the prologue of the Linear that reads it (linear(ln=...)): 0 = never, 1 = where it measured as a gain (every
-        # K <= 320 pair; K <= 640 without the GEGLU epilogue), 2 = wherever the library takes the pair
+        # LayerNorm in the prologue of the Linear that reads it (linear(ln=...)): 0 = never, 1 = where it measured as a gain (K <= 320,
+        # the 128-row register image: +2 ... +13 us per pair at M = 32 768; the 64-row image of K <= 640 loses 0 ... 20 us to the
+        # ring kernels it displaces - tools/ln_fuse_bench.py), 2 = wherever the library takes the pair
         self.fuse_ln = int(os.environ.get("PDMK_FUSE_LN", "1"))
         self.fuse_geglu_bwd = os.environ.get("PDMK_FUSE_GEGLU_BWD", "1") != "0"   # same for the backward (ff.net.2's input gradient)
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
@@ -217,7 +218,7 @@ class UNetEngine:
         a_t, ln_args, ln_src = x.t, None, None             # forward A operand; the LayerNorm prologue of the GEMM, its input Act
         if ln is not None:
             take = (self.fuse_ln and self.dtype == torch.bfloat16 and not skinny and residual is None and out is None and
-                    not out_f32 and cs is None and (self.fuse_ln >= 2 or Kp <= 320 or not geglu) and
+                    not out_f32 and cs is None and (self.fuse_ln >= 2 or Kp <= 320) and
                     k.gemm_ln_supported(x.t, P.wv(key + ".weight"), M, Np, Kp, _ld(x.t), Kp, geglu=geglu, bias=bool(bias)))
             if not take:
                 x = self.layernorm(x, ln)
