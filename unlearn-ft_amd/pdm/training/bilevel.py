@@ -400,7 +400,9 @@ class BilevelStepper:
             # host side of the stream - under lockstep recording the kernels are issued later)
             t2 = torch.cat([timesteps, timesteps], 0)
             noisy2, _ = self._diffuse(torch.cat([latents, latents], 0), torch.cat([noise, noise], 0), t2, False)
-            ehs2 = torch.cat([self._ehs2d(prompt_embeds), self._ehs2d(empty_prompt_embeds)], 0)
+            # (... which is why the two prompt batches are concatenated BEFORE the cast: _ehs2d's cast is a recorded kernel, and a
+            # torch.cat of its two outputs would run at once, on memory the cast has not written yet)
+            ehs2 = self._ehs2d(torch.cat([prompt_embeds.to(self.dev), empty_prompt_embeds.to(self.dev)], 0))
             return self.teacher.forward_nhwc(noisy2, t2, ehs2, 2 * B, H, W, train=False)
 
     def student_forward(self, latents, noise, timesteps, prompt_embeds, train=True, input_noise=None, want_target=True):
