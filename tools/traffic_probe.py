@@ -15,7 +15,9 @@ dev, dt, NBUF, REP = torch.device("cuda:0"), torch.bfloat16, 6, 12
 # (M, N, K, mode)
 SHAPES = [(32768, 320, 320, "plain"), (32768, 320, 320, "bias+res"), (32768, 320, 320, "acc"), (32768, 960, 320, "plain"),
           (32768, 160, 320, "plain"), (8192, 640, 640, "plain"), (8192, 640, 640, "bias+res")]
-cands = [int(c) for c in sys.argv[1:]] or [12]
+CONVS = [(8, 64, 320, 320), (8, 64, 640, 320), (8, 32, 640, 640), (8, 64, 960, 320)]      # (B, H, Ci, Co), stride-1 3x3
+conv_cands = [int(c[1:]) for c in sys.argv[1:] if c.startswith("c")]
+cands = [int(c) for c in sys.argv[1:] if not c.startswith("c")] or ([] if conv_cands else [12])
 print("order of launches (REP each):")
 for c in cands:
     os.environ["PDMK_RING_CFG"] = str(c)
@@ -34,3 +36,19 @@ for c in cands:
         alg_r = 2 * (M * K + N * K + (M * N if mode in ("bias+res", "acc") else 0))
         alg_w = 2 * M * N
         print(f"VARIANT cand={c} M={M} N={N} K={K} mode={mode} reps={REP} alg_read={alg_r} alg_write={alg_w} kernel={name}", flush=True)
+
+for c in conv_cands:
+    os.environ["PDMK_RING_CFG"] = str(c)
+    for B, H, Ci, Co in CONVS:
+        M = B * H * H
+        xs = [torch.randn(M, Ci, device=dev).to(dt) for _ in range(NBUF)]
+        ws = [(torch.randn(Co, 9 * Ci, device=dev) * (9 * Ci) ** -0.5).to(dt) for _ in range(NBUF)]
+        ys = [torch.zeros(M, Co, device=dev, dtype=dt) for _ in range(NBUF)]
+        bias = torch.randn(Co, device=dev)
+        torch.cuda.synchronize()
+        for r in range(REP):
+            i = r % NBUF
+            k.gemm(xs[i], ws[i], ys[i], M, Co, 9 * Ci, 0, 9 * Ci, Co, a_mode=k.A_CONV, conv=(B, H, H, Ci, H, H, 0, Ci), bias=bias)
+        torch.cuda.synchronize()
+        name = k.candidate_name(k.A_CONV, k.B_ROWK, k.last_candidate())
+        print(f"VARIANT cand={c} M={M} N={Co} K={9 * Ci} mode=conv{H}x{H} reps={REP} alg_read={2 * (M * Ci + Co * 9 * Ci)} alg_write={2 * M * Co} kernel={name}", flush=True)

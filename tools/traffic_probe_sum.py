@@ -11,7 +11,7 @@ for l in open(sys.argv[1]):
 def load(d):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if ("igemm_ring" in r["Kernel_Name"] or "rowblock" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"])]
+        rows += [r for r in csv.DictReader(open(f)) if ("igemm_ring" in r["Kernel_Name"] or "rowblock" in r["Kernel_Name"] or "igemm_kernel" in r["Kernel_Name"] or "conv_halo" in r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r.get("Dispatch_Id", r.get("Dispatch_ID", 0))))
     return rows
 fe, wr = load(sys.argv[2]), load(sys.argv[3])

@@ -1163,8 +1163,8 @@ int pdmk_gemm_ring_name(int id, int conv, char* buf, int n) {      // the demang
     if (id < 0) return -1;
     if (id >= kNumBase && id < kNumBase + kNumHalo) {
         const int h = id - kNumBase;
-        snprintf(buf, n, "pdmk_ring::conv_halo_kernel<%d, %d, %d, %d>", h < 2 ? 256 : 128, (h & 1) ? 4 : 5,
-                 h < 2 ? 3 : ((h & 1) ? 5 : 4), h < 2 ? 400 : 264);
+        snprintf(buf, n, "pdmk_ring::conv_halo_kernel<%d, %d, %d, %d, 9>", h < 2 ? 256 : 128, (h & 1) ? 4 : 5,
+                 h < 2 ? 3 : ((h & 1) ? 5 : 4), h < 2 ? 400 : 264);          // (2x2 phase launches run the <..., 4> instantiation)
         return 0;
     }
     const Config c = kConfigs[id < kNumBase ? id : id - kNumHalo];
