@@ -580,6 +580,7 @@ def wgrad(dy, x, dW, M, N, K, lda, ldb, *, b_mode=B_COLK, conv=None, colsum_out=
 
 _WG_TARGET = int(os.environ.get("PDMK_WG_TARGET", "512"))     # workgroups a block's grouped weight-gradient launch aims for
 _WG_MINK = int(os.environ.get("PDMK_WG_MINK", "32"))           # and the fewest 64-row K-steps a split may be left with
+_WG_CONV_SLABS = os.environ.get("PDMK_WGRAD_SLABS_CONV", "0") == "1"   # grouped 3x3 conv weight gradients: split partials to slabs (1) or fp32 atomics (0)
 
 
 def wgrad_group(items, queue, target_wgs=None):
@@ -608,9 +609,9 @@ def wgrad_group(items, queue, target_wgs=None):
         with Recorder() as r:
             slabs = []
             for dy, x, dW, M, N, K_, lda, ldb, cs, macs, bm_, conv in same:
-                if not conv_g and sk > 1 and (M * N) % 4 == 0 and dW.is_contiguous():
+                if (not conv_g or _WG_CONV_SLABS) and queue is not None and sk > 1 and (M * N) % 4 == 0 and dW.is_contiguous():
                     ws = torch.empty(sk * M * N, device=dy.device, dtype=torch.float32)
-                    gemm(dy, x, ws, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=bm_, out_f32=True, splitk=sk, accumulate=2,
+                    gemm(dy, x, ws, M, N, K_, lda, ldb, N, a_mode=A_COLK, b_mode=bm_, conv=conv, out_f32=True, splitk=sk, accumulate=2,
                          dtype=dt(x), macs=macs, colsum_out=cs)
                     slabs.append((ws, dW, M * N, sk))
                 else:       # unsplit: added into the gradient in the epilogue; conv splits: fp32 atomics into it

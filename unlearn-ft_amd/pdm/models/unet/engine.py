@@ -375,8 +375,7 @@ class UNetEngine:
                 dy = out.g
                 ldy = _ld(dy)
                 xt = x.t
-                collect = (self._wg_items is not None and self.group_conv_wgrad and not self.wgrad_async and not self.conv_slabs
-                           and mode == 0)
+                collect = self._wg_items is not None and self.group_conv_wgrad and not self.wgrad_async and mode == 0
                 if collect:      # conv1 / conv2 of a ResBlock: one grouped launch at the block's start marker
                     self._wg_items.append((dy, xt, P.g(key + ".weight"), Cop, 9 * Cip, M, ldy, 0, P.g(bias), lmacs, k.B_COLK_CONV,
                                            (B, Hi, Wi, Cip, Ho, Wo, mode, _ld(xt))))
