@@ -1037,6 +1037,25 @@ def test_wgrad_group_of_a_transformer_block_matches_separate_launches(dev):
         if rb is not None:
             close(it[8], rb, 2e-3, "grouped bias gradient")
             close(it[8], sb, 1e-4, "grouped vs separate bias gradient")
+    # the two 3x3 conv weight gradients of a ResBlock as one group (atomics for the splits), against the separate launches
+    Bc, Hc = 2, 32
+    Pc = Bc * Hc * Hc
+    citems, cseps = [], []
+    for Co, Ci in ((160, 64), (96, 160)):
+        dy, x = rnd((Pc, Co), dev, dt), rnd((Pc, Ci), dev, dt)
+        dW = torch.randn(Co, 9 * Ci, device=dev) * 0.1
+        db = torch.randn(Co, device=dev) * 0.1
+        conv = (Bc, Hc, Hc, Ci, Hc, Hc, 0, Ci)
+        dW2, db2 = dW.clone(), db.clone()
+        k.wgrad(dy, x, dW2, Co, 9 * Ci, Pc, Co, 0, b_mode=k.B_COLK_CONV, conv=conv, colsum_out=db2)
+        cseps.append((dW2, db2))
+        citems.append((dy, x, dW, Co, 9 * Ci, Pc, Co, 0, db, Co * 9 * Ci * Pc, k.B_COLK_CONV, conv))
+    k.wgrad_group(citems, q)
+    q.flush()
+    torch.cuda.synchronize()
+    for it, (sW, sb) in zip(citems, cseps):
+        close(it[2], sW, 1e-4, "grouped vs separate conv weight gradient")
+        close(it[8], sb, 1e-4, "grouped vs separate conv bias gradient")
 
 
 def test_comm_handle_single_rank_allreduce(dev):
