@@ -463,6 +463,11 @@ def main():
                 "traffic_source": (f"committed profile profiles/{os.path.basename(tfile)} (separate rocprofv3 --pmc FETCH_SIZE / "
                                    f"WRITE_SIZE passes of this command, gfx950 2x FETCH_SIZE correction, keyed by kernel symbol; "
                                    f"not measured in this run: counters cannot be read live)") if traffic else None,
+                # what the ratio is made of for the halo conv (isolated probes, profiles/r04_traffic_probe_conv.txt): the (R + 2) / R halo
+                # rows of an R-image-row tile fetched by both neighbours at once and one copy of the weights per XCD L2; FETCH_SIZE also
+                # counts requests the Infinity Cache serves, so this is fabric traffic - an upper bound of HBM traffic
+                "traffic_note": ("halo rows (x (R+2)/R per tile of R image rows) + one weight copy per XCD L2; fabric requests incl. "
+                                 "Infinity-Cache hits (DESIGN.md 5.0)") if (traffic and "conv_halo" in sym(dom[0])) else None,
                 "launches": dom[1][2], "avg_launch_ms": round(dom[1][1] / dom[1][2], 4),
                 "two_sided": {"note": "per launch max(MACs/2.5 PFLOP/s, algorithmic bytes/8 TB/s) summed, over measured time; "
                                       "three_sided adds the L2->LDS operand intake of the best 512-thread tile at 70 GB/s per CU",
