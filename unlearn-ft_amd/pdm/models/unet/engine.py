@@ -143,7 +143,13 @@ class UNetEngine:
         into - it waits as the pending addend even when it is the first gradient to arrive."""
         if not act.rg:
             return
-        if act._g is None and park and act.pend is None:
+        if act._g is None and act.pend is not None:
+            # a parked first gradient and now a second finished one (no topology of the shipped recipes does this): the sum gets a
+            # buffer of its own - neither finished buffer may be written
+            p_, act.pend = act.pend, None
+            act.g = self._empty(p_.shape[0], p_.shape[1], act.t.dtype)
+            k.copy2d(p_, act._g, p_.shape[0], p_.shape[1], _ld(p_), _ld(act._g))
+        if act._g is None and park:
             act.pend = dy
             act.parked = True
         elif act._g is None:
