@@ -20,6 +20,9 @@
 #ifndef PDMK_HALO_PAIRS
 #define PDMK_HALO_PAIRS 1     // halo conv, rings of >= 4 slots: two taps per barrier (0: one, as in round 1)
 #endif
+#ifndef PDMK_HALO_SPLIT_ISSUE
+#define PDMK_HALO_SPLIT_ISSUE 1   // ... and the event's DMA issue split by wave half (conv_halo_body)
+#endif
 
 namespace pdmk_ring {
 
@@ -736,32 +739,45 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
                 const int cbn = last ? cb + 1 : cb, tn0 = last ? 0 : t0 + 2;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                int sl = slot_c + ne;
-                sl = sl >= BSTAGES ? sl - BSTAGES : sl;
+                // The event's DMA instructions (next event's weight tiles, pieces of the next block's patch: 6-8 per wave) go into
+                // slots nobody reads during this event, so they can be issued anywhere inside it.  All eight waves issuing them
+                // together right behind the barrier hold each other in the memory pipe (~140 cycles per piece) while
+                // the matrix pipes idle: waves 0-3 issue first, their SIMD partners 4-7 multiply the first tap first and issue between
+                // the taps (PDMK_HALO_SPLIT_ISSUE=0: all waves first)
+                const int slot_c0 = slot_c;
+                auto issue_all = [&]() __attribute__((always_inline)) {
+                    int sl = slot_c0 + ne;
+                    sl = sl >= BSTAGES ? sl - BSTAGES : sl;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u < nn) {
-                        issue_b(cbn, tn0 + u, sl);
-                        sl = sl + 1 == BSTAGES ? 0 : sl + 1;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u < ne) {
-#pragma unroll
-                        for (int q = 0; q < PPT; ++q) {                   // PPT patch pieces of the next block per tap
-                            const int t = (t0 + u) * PPT + q;
-                            const bool own = t < NPW && (t * 8 + wave) * 8 < prows;
-                            issue_piece(cb + 1, own ? poff[t < NPW ? t : 0] : poff[0], own ? t : 0);
+                    for (int u = 0; u < 2; ++u) {
+                        if (u < nn) {
+                            issue_b(cbn, tn0 + u, sl);
+                            sl = sl + 1 == BSTAGES ? 0 : sl + 1;
                         }
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u < ne) {
-                        tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + u);
-                        slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
+                    for (int u = 0; u < 2; ++u) {
+                        if (u < ne) {
+#pragma unroll
+                            for (int q = 0; q < PPT; ++q) {               // PPT patch pieces of the next block per tap
+                                const int t = (t0 + u) * PPT + q;
+                                const bool own = t < NPW && (t * 8 + wave) * 8 < prows;
+                                issue_piece(cb + 1, own ? poff[t < NPW ? t : 0] : poff[0], own ? t : 0);
+                            }
+                        }
                     }
+                };
+                // (measured, tools/conv_ab.py, B = 8: the 128 x 160 tiles gain 2.5-12 % - 64^2 320 -> 320 79.1 -> 70.5 us, 32^2 640 -> 640
+                // 62.6 -> 59.4 - the 128 x 128 tiles LOSE 1-9 % - 960 -> 320 210.7 -> 229.7 us: with 16 MFMAs per tap and two pieces per
+                // weight tile their partners finish the first tap before the early half is out of the memory pipe - so NJ = 5 only)
+                const bool late = PDMK_HALO_SPLIT_ISSUE && NJ >= 5 && wave >= 4 && ne == 2;      // wave-uniform
+                if (!late) issue_all();
+                tap_compute(pbuf, bring + slot_c * B_BYTES, t0);
+                slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
+                if (late) issue_all();
+                if (ne == 2) {
+                    tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + 1);
+                    slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
                 }
             }
         }
