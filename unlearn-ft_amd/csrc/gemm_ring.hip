@@ -20,6 +20,11 @@
 #ifndef PDMK_HALO_PAIRS
 #define PDMK_HALO_PAIRS 1     // halo conv, rings of >= 4 slots: two taps per barrier (0: one, as in round 1)
 #endif
+#ifndef PDMK_RING_SPLIT_ISSUE
+#define PDMK_RING_SPLIT_ISSUE 0   // ring GEMM: a stage's DMA issue split by wave half (igemm_ring_body).  Measured (round 4): +-0 on the C x C shapes
+                                  // in isolation, -0.5 % for the step (187.8 -> 186.9 images/s) - unlike the halo conv, whose events carry 6-8 pieces
+                                  // per wave against 20-40 MFMAs, a ring stage is 3-5 pieces against 20 - so it is OFF
+#endif
 #ifndef PDMK_HALO_SPLIT_ISSUE
 #define PDMK_HALO_SPLIT_ISSUE 1   // ... and the event's DMA issue split by wave half (conv_halo_body)
 #endif
@@ -491,7 +496,11 @@ __device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigne
             wait_vmcnt_dyn(min(STAGES - 2, kt1 - 1 - kt) * ndma);
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
+        // the stage's DMA instructions go into the slot read LAST step: anywhere inside this step will do.  Waves 0-3 issue them
+        // first, their SIMD partners 4-7 between the two halves of the step's MFMAs (PDMK_RING_SPLIT_ISSUE; as in conv_halo_body:
+        // eight waves in the memory pipe together right behind the barrier leave the matrix pipes idle)
+        const bool late = PDMK_RING_SPLIT_ISSUE && wave >= 4;        // wave-uniform
+        if (!late && kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
         const unsigned char* sa = smem + slot * SLOT;
         const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
@@ -506,6 +515,11 @@ __device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigne
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            if (kk == 0 && late) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
