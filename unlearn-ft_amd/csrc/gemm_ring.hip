@@ -26,7 +26,8 @@
                                   // per wave against 20-40 MFMAs, a ring stage is 3-5 pieces against 20 - so it is OFF
 #endif
 #ifndef PDMK_HALO_SPLIT_ISSUE
-#define PDMK_HALO_SPLIT_ISSUE 1   // ... and the event's DMA issue split by wave half (conv_halo_body)
+#define PDMK_HALO_SPLIT_ISSUE 1   // ... and the event's DMA issue split by wave half (conv_halo_body); 2 = four issue points (waves 2, 3 / 6, 7 between
+                                  // a tap's two MFMA groups): measured 3-9 % SLOWER than 1 (64^2 320 -> 320: 71.2 -> 77.5 us), off
 #endif
 
 namespace pdmk_ring {
@@ -696,10 +697,11 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
 
     // one tap: 2 x (IM x NJ) MFMAs out of the patch (shifted rows) and one weight tile
     int ta = ta0, tb = tb0;                                          // tap phase of the block being multiplied
-    auto tap_compute = [&](const unsigned char* pbuf, const unsigned char* sb, int tap) __attribute__((always_inline)) {
+    auto tap_compute = [&](const unsigned char* pbuf, const unsigned char* sb, int tap, auto&& mid) __attribute__((always_inline)) {
         const int toff = NTAPS == 4 ? (ta + (tap >> 1)) * W2 + (tb + (tap & 1)) : (tap / 3) * W2 + (tap % 3);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 1) mid();                      // (an issue point between the tap's two MFMA groups: conv_halo_body's event loop)
             bf16x8 af[IM], bf[NJ];
 #pragma unroll
             for (int i = 0; i < IM; ++i) {
@@ -784,13 +786,19 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
                 // (measured, tools/conv_ab.py, B = 8: the 128 x 160 tiles gain 2.5-12 % - 64^2 320 -> 320 79.1 -> 70.5 us, 32^2 640 -> 640
                 // 62.6 -> 59.4 - the 128 x 128 tiles LOSE 1-9 % - 960 -> 320 210.7 -> 229.7 us: with 16 MFMAs per tap and two pieces per
                 // weight tile their partners finish the first tap before the early half is out of the memory pipe - so NJ = 5 only)
-                const bool late = PDMK_HALO_SPLIT_ISSUE && NJ >= 5 && wave >= 4 && ne == 2;      // wave-uniform
-                if (!late) issue_all();
-                tap_compute(pbuf, bring + slot_c * B_BYTES, t0);
+                // issue point of this wave: 0 = before the first tap, 2 = between the taps (PDMK_HALO_SPLIT_ISSUE >= 1, by wave half);
+                // PDMK_HALO_SPLIT_ISSUE == 2 adds 1 / 3 = between the two MFMA groups of the first / second tap (waves 2, 3 / 6, 7)
+                const int ip = (PDMK_HALO_SPLIT_ISSUE && NJ >= 5 && ne == 2)
+                                   ? ((wave >= 4 ? 2 : 0) + ((PDMK_HALO_SPLIT_ISSUE == 2 && (wave & 2)) ? 1 : 0)) : 0;   // wave-uniform
+                auto nomid = [&]() __attribute__((always_inline)) {};
+                if (ip == 0) issue_all();
+                if (PDMK_HALO_SPLIT_ISSUE == 2) tap_compute(pbuf, bring + slot_c * B_BYTES, t0, [&]() __attribute__((always_inline)) { if (ip == 1) issue_all(); });
+                else tap_compute(pbuf, bring + slot_c * B_BYTES, t0, nomid);
                 slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
-                if (late) issue_all();
+                if (ip == 2) issue_all();
                 if (ne == 2) {
-                    tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + 1);
+                    if (PDMK_HALO_SPLIT_ISSUE == 2) tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + 1, [&]() __attribute__((always_inline)) { if (ip == 3) issue_all(); });
+                    else tap_compute(pbuf, bring + slot_c * B_BYTES, t0 + 1, nomid);
                     slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
                 }
             }
@@ -845,7 +853,7 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
                         else issue_piece(cb + 1, poff[0], 0);
                     }
                 }
-                tap_compute(pbuf, bring + slot_c * B_BYTES, tap);
+                tap_compute(pbuf, bring + slot_c * B_BYTES, tap, []() {});
                 slot_c = slot_c + 1 == BSTAGES ? 0 : slot_c + 1;
             }
         }
