@@ -529,6 +529,8 @@ def main():
                                       + (" [TINY DEBUG TOPOLOGY - not the benchmark]" if a.tiny else ""),
                           "global_batch": B * world, "parallelism": f"dp{world}", "student_params": student.num_parameters(),
                           "weights": "random-init",
+                          # "activation dtype" unless PDMK_ATTN_FP8=1 rounds Q/K/V to e4m3 (configs[4]; never the default line)
+                          "attention_precision": student.attention_precision or "activation dtype",
                           # what the ranks really talked over (the driver's SCALE record can be checked against it)
                           "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
                           "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),

@@ -311,6 +311,13 @@ int pdmk_geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ld
                    int dtype, pdmk_stream stream);
 /* y = silu(x) over n contiguous elements (time-embedding MLP, blocks.py:336); bwd: dx = dy * silu'(x). */
 int pdmk_silu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_stream stream);
+/* y = x rounded to the nearest OCP e4m3fn value (round-half-even, saturating at +-448, subnormal step 2^-9), kept in `dtype`
+ * (in place allowed).  The precision option of BASELINE.json configs[4] ("fp8 MFMA attention path"; the reference itself has no fp8
+ * code - HeadGatedAttnProcessor2, blocks.py:257-277, runs F.scaled_dot_product_attention in the activation dtype): with
+ * `attention_precision = "fp8_e4m3"` the engine rounds Q, K and V to this grid before the attention kernels, in the forward pass and
+ * - the same tensors - in the backward recomputation; every product of two such values is exact in the bf16 MFMA the kernels use, so
+ * the QK^T scores are what v_mfma_f32_16x16x32_fp8_fp8 would accumulate (why that instruction itself is not used: DESIGN.md 10). */
+int pdmk_quantize_e4m3(const void* x, void* y, int64_t n, int dtype, pdmk_stream stream);
 int pdmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, pdmk_stream stream);
 /* Strided 2-D copy / accumulate between [rows, cols] views (skip concat torch.cat(dim=1) and its backward,
  * gradient fan-in of residual / skip connections): dst = (accumulate ? dst : 0) + src. */

@@ -22,6 +22,26 @@ from .config import UNetConfig
 # next conv / linear casts to bf16 once), and the fused F.scaled_dot_product_attention (blocks.py:257-277) keeps QK^T and the
 # softmax in fp32, rounding only P to bf16 for the PV product.
 FP32_NORMS = False
+# "fp8_e4m3" attention precision (BASELINE.json configs[4]; no counterpart in the reference, whose attention runs in the activation
+# dtype, blocks.py:257-277): Q, K and V rounded to the nearest OCP e4m3fn value before QK^T and PV, gradients straight through.
+ATTN_FP8 = False
+
+
+def quant_e4m3(x):
+    """Nearest e4m3fn value (4 exponent bits, bias 7, 3 mantissa bits; max 448; subnormal step 2^-9), round-half-even,
+    saturating; same dtype as x.  torch.frexp / ldexp / round are exact here, so this IS the rounding, not an approximation."""
+    xf = x.float()
+    ax = xf.abs().clamp(max=448.0)
+    _, ex = torch.frexp(ax)                              # ax = m * 2^ex, m in [0.5, 1)  ->  floor(log2 ax) = ex - 1
+    e = (ex - 1).clamp(min=-6) - 3
+    q = torch.ldexp(torch.ones_like(ax), e)
+    r = torch.round(ax / q) * q
+    out = torch.where(torch.isnan(xf), xf, torch.copysign(r, xf))
+    return out.to(x.dtype)
+
+
+def _fq(x):
+    return x + (quant_e4m3(x) - x).detach() if ATTN_FP8 else x
 
 
 def _gn(x, groups, w, b, eps):
@@ -63,6 +83,7 @@ def attention(sd, p, x, ctx, heads, head_dim):
     q = F.linear(x, sd[p + ".to_q.weight"]).view(B, N, heads, head_dim).transpose(1, 2)
     k = F.linear(src, sd[p + ".to_k.weight"]).view(B, -1, heads, head_dim).transpose(1, 2)
     v = F.linear(src, sd[p + ".to_v.weight"]).view(B, -1, heads, head_dim).transpose(1, 2)
+    q, k, v = _fq(q), _fq(k), _fq(v)
     if FP32_NORMS and q.dtype != torch.float32:      # fused SDPA numerics: fp32 scores and softmax, P rounded once
         with torch.autocast("cpu", enabled=False):
             s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * (head_dim ** -0.5)

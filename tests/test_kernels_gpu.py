@@ -1058,6 +1058,28 @@ def test_wgrad_group_of_a_transformer_block_matches_separate_launches(dev):
         close(it[8], sb, 1e-4, "grouped vs separate conv bias gradient")
 
 
+@pytest.mark.parametrize("dn", ["f32", "bf16"])
+def test_quantize_e4m3_matches_the_oracle_bit_for_bit(dev, dn):
+    """pdmk_quantize_e4m3 (the "fp8_e4m3" attention precision of BASELINE.json configs[4]): in-place rounding to the e4m3fn value grid,
+    bit-identical to the oracle's quant_e4m3 (itself equal to torch's float8_e4m3fn cast, tests/test_oracle_golden.py) on random
+    values over five decades, ties, subnormals, the saturation edge and NaN; a length that leaves a scalar tail."""
+    from pdm import _pdmk as k
+    from pdm_ref import unet as ounet
+    torch.manual_seed(8)
+    dt = DT[dn]
+    x = torch.cat([torch.randn(30001) * 3, torch.randn(3000) * 100, torch.randn(3000) * 0.01,
+                   torch.tensor([0.0, -0.0, 448.0, 449.0, 1e6, -1e6, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 17.0, 19.0, -17.0,
+                                 float("nan")])]).to(dt)
+    want = ounet.quant_e4m3(x)
+    got = x.clone().to(dev)
+    k.quantize_e4m3_(got)
+    torch.cuda.synchronize()
+    got = got.cpu()
+    nan = torch.isnan(want.float())
+    assert torch.equal(torch.isnan(got.float()), nan)
+    assert torch.equal(got.float()[~nan], want.float()[~nan])
+
+
 def test_comm_handle_single_rank_allreduce(dev):
     """pdmk_comm_t (the C ABI's communicator handle): id -> create -> in-place fp32 all-reduce(sum) on a side stream ->
     destroy, on a world of one rank (all this one-GPU box can host: RCCL refuses two ranks on one device; the N-rank

@@ -252,3 +252,31 @@ def test_loss_heads_match_reference_statements():
         assert torch.allclose(pred.grad, tt(p + "dpred"), rtol=1e-5, atol=1e-8)
         got = acts_s["m"].grad if acts_s["m"].grad is not None else torch.zeros_like(acts_s["m"])
         assert torch.allclose(got, tt(p + "dact_m"), rtol=1e-5, atol=1e-9)
+
+
+def test_oracle_e4m3_quantiser_is_torchs_float8_cast():
+    """pdm_ref.unet.quant_e4m3 (the value grid of the "fp8_e4m3" attention precision, BASELINE.json configs[4]) against torch's own
+    float8_e4m3fn cast: random values over five decades, exact ties (round-half-even), subnormals, the saturation edge, signed zeros;
+    NaN stays NaN."""
+    import torch
+    from pdm_ref import unet as U
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(50000, generator=g) * 3, torch.randn(5000, generator=g) * 100, torch.randn(5000, generator=g) * 0.01,
+                   torch.tensor([0.0, -0.0, 448.0, 447.9, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.5 * 2.0 ** -9, 0.0625, 15.5, 17.0, 18.0,
+                                 19.0, 20.0, -17.0, -19.0, 2.0 ** -6, 0.9 * 2.0 ** -6])])
+    q = U.quant_e4m3(x)
+    assert torch.equal(q, x.to(torch.float8_e4m3fn).float())
+    assert torch.equal(U.quant_e4m3(torch.tensor([449.0, 1e6, -1e6])), torch.tensor([448.0, 448.0, -448.0]))       # saturating
+    assert torch.isnan(U.quant_e4m3(torch.tensor([float("nan")]))).all()
+    xb = (torch.randn(4000, generator=g) * 4).bfloat16()
+    qb = U.quant_e4m3(xb)
+    assert qb.dtype == torch.bfloat16 and torch.equal(qb.float(), xb.float().to(torch.float8_e4m3fn).float())
+    # straight-through gradient, and off by default
+    U.ATTN_FP8 = True
+    try:
+        t = torch.randn(8, requires_grad=True)
+        U._fq(t).sum().backward()
+        assert torch.equal(t.grad, torch.ones(8))
+    finally:
+        U.ATTN_FP8 = False
+    assert U._fq(x) is x

@@ -287,6 +287,18 @@ __device__ __forceinline__ float silu_grad_f(float x) {
     const float s = sigmoid_fast(x);
     return s * (1.0f + x * (1.0f - s));
 }
+// Round to the nearest OCP e4m3fn value (4 exponent bits, bias 7, 3 mantissa bits; largest 448, subnormal step 2^-9), ties to
+// even, saturating - the value grid of the fp8 MFMA operands (BASELINE configs[4]: "fp8 MFMA attention path").  Plain fp32
+// arithmetic on purpose (no v_cvt_pk_fp8_f32): x / q is exact for a power of two q, rintf is round-half-even, so the result
+// is bit-identical to the oracle's torch statement of the same formula on every input, NaN included.
+__device__ __forceinline__ float quant_e4m3_f(float x) {
+    if (!(x == x)) return x;
+    const float ax = fminf(fabsf(x), 448.0f);
+    int e = (int)((__float_as_uint(ax) >> 23) & 0xffu) - 127;        // floor(log2 ax) (ax = 0 / fp32 subnormal: -127)
+    e = (e < -6 ? -6 : e) - 3;                                        // exponent of the quantum: 3 mantissa bits, subnormals below 2^-6
+    const float q = __uint_as_float((unsigned)(e + 127) << 23);
+    return copysignf(rintf(ax / q) * q, x);
+}
 // erf-GELU (GEGLU's gate, blocks.py:55) with erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: far inside the fp32
 // parity tolerance) on the hardware exp2 / rcp; erf(x / sqrt 2) and the Gaussian of the derivative share ONE exponential.
 // libm erff + expf are ~50 VALU instructions per element and made the GEGLU kernels VALU-bound.

@@ -70,7 +70,7 @@ int geglu_bwd(const void* x, const void* dy, void* dx, int M, int F, int ldx, in
 }
 
 // ------------------------------------------------------------------------------------------------ SiLU / AXPBY
-template <typename T, int OP>   // 0 silu fwd, 1 silu bwd (y=dy in, out=dx), 2 axpby, 3 erf-gelu fwd
+template <typename T, int OP>   // 0 silu fwd, 1 silu bwd (y=dy in, out=dx), 2 axpby, 3 erf-gelu fwd, 4 round to e4m3 values
 __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* __restrict__ y, long n, float alpha,
                           float beta) {
     constexpr int V = Vec<T>::N;
@@ -88,6 +88,9 @@ __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* _
         } else if (OP == 3) {
 #pragma unroll
             for (int e = 0; e < V; ++e) o[e] = gelu_f(f[e]);
+        } else if (OP == 4) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) o[e] = quant_e4m3_f(f[e]);
         } else {
             Vec<T>::load(y + i * V, o);
 #pragma unroll
@@ -102,6 +105,7 @@ __global__ void ew_kernel(const T* __restrict__ x, const T* __restrict__ a, T* _
         if (OP == 0) o = silu_f(f);
         else if (OP == 1) o = to_f32(a[i]) * silu_grad_f(f);
         else if (OP == 3) o = gelu_f(f);
+        else if (OP == 4) o = quant_e4m3_f(f);
         else o = alpha * f + beta * to_f32(y[i]);
         y[i] = from_f32<T>(o);
     }
@@ -791,6 +795,12 @@ extern "C" int pdmk_silu_fwd(const void* x, void* y, int64_t n, int dtype, pdmk_
     if (!x || !y || n <= 0) return -1;
     if (dtype == PDMK_BF16) return ew<bf16, 0>(x, x, y, n, 0, 0, (hipStream_t)s);
     if (dtype == PDMK_F32) return ew<float, 0>(x, x, y, n, 0, 0, (hipStream_t)s);
+    return -2;
+}
+extern "C" int pdmk_quantize_e4m3(const void* x, void* y, int64_t n, int dtype, pdmk_stream s) {
+    if (!x || !y || n <= 0) return -1;
+    if (dtype == PDMK_BF16) return ew<bf16, 4>(x, x, y, n, 0, 0, (hipStream_t)s);
+    if (dtype == PDMK_F32) return ew<float, 4>(x, x, y, n, 0, 0, (hipStream_t)s);
     return -2;
 }
 extern "C" int pdmk_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, pdmk_stream s) {

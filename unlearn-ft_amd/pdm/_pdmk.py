@@ -73,6 +73,7 @@ _SIGS = {
                        i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, i64, i32, f32, vp, i64, i32, vp], i32),
     "pdmk_geglu_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     "pdmk_geglu_bwd": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    "pdmk_quantize_e4m3": ([vp, vp, i64, i32, vp], i32),
     "pdmk_silu_fwd": ([vp, vp, i64, i32, vp], i32),
     "pdmk_silu_bwd": ([vp, vp, vp, i64, i32, vp], i32),
     "pdmk_copy2d": ([vp, vp, i64, i32, i32, i32, i32, i32, vp], i32),
@@ -817,6 +818,13 @@ def gemm_geglu_bwd(dy, wt, pre, dpre, M, N, K, lddy, ldwt, *, macs=None):
         PROFILE.append((("bf16", A_ROWK, B_ROWK, _lib.pdmk_gemm_last_candidate()), 2.0 * (macs if macs is not None else M * N * K),
                         e0, e1, (M, N, K, 1)))
     return True
+
+
+@_recordable("quantize_e4m3")
+def quantize_e4m3_(x):
+    """In place: every element of the contiguous tensor x rounded to the nearest e4m3fn value (pdmk_quantize_e4m3)."""
+    assert x.is_contiguous()
+    _chk(_lib.pdmk_quantize_e4m3(_p(x), _p(x), x.numel(), dt(x), _st()), "pdmk_quantize_e4m3")
 
 
 @_recordable("silu_fwd")

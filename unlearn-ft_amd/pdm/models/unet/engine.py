@@ -84,6 +84,8 @@ class UNetEngine:
         # the 128-row register image: +2 ... +13 us per pair at M = 32 768; the 64-row image of K <= 640 loses 0 ... 20 us to the
         # ring kernels it displaces - tools/ln_fuse_bench.py), 2 = wherever the library takes the pair
         self.fuse_ln = int(os.environ.get("PDMK_FUSE_LN", "1"))
+        # "fp8_e4m3" attention precision (UNet2DConditionModelPruned.set_attention_precision): Q / K / V rounded to e4m3fn values
+        self.attn_fp8 = False
         self.fuse_geglu_bwd = os.environ.get("PDMK_FUSE_GEGLU_BWD", "1") != "0"   # same for the backward (ff.net.2's input gradient)
         self.defer_fanin = os.environ.get("PDMK_DEFER_FANIN", "1") != "0"   # A/B switch: 0 = residual gradients added at once
         self._keep = []                # operands of in-flight side-stream kernels (freed only after a join)
@@ -742,10 +744,14 @@ class UNetEngine:
         n = self.groupnorm(x, p + ".norm", B, N, G, c // G, 1e-6, False)
         h = self.linear(n, p + ".proj_in", bias=p + ".proj_in.bias")
         qkv = self.linear(h, t + ".attn1.to_qkv", ln=t + ".norm1")
+        if self.attn_fp8:            # in place: the backward pass recomputes the scores from the same rounded operands
+            k.quantize_e4m3_(qkv.t)
         o = self.attention(qkv.t[:, :d1], qkv.t[:, d1:2 * d1], qkv.t[:, 2 * d1:3 * d1], B, a.h1(), N, N, qkv, qkv,
                            (0, d1), ((d1, 2 * d1), (2 * d1, 3 * d1)), tag=t + ".attn1")
         h = self.linear(o, t + ".attn1.to_out.0", bias=t + ".attn1.to_out.0.bias", residual=h)
         q = self.linear(h, t + ".attn2.to_q", ln=t + ".norm2")
+        if self.attn_fp8:
+            k.quantize_e4m3_(q.t)
         kv, ko = ehs, self.kv_lay[p][0]      # `ehs` = the batched K/V projection of all transformers; this one's columns
         o = self.attention(q.t[:, :d2], kv.t[:, ko:ko + d2], kv.t[:, ko + d2:ko + 2 * d2], B, a.h2(), N, T, q, kv, (0, d2),
                            ((ko, ko + d2), (ko + d2, ko + 2 * d2)), tag=t + ".attn2")
@@ -787,6 +793,8 @@ class UNetEngine:
         if self.kv_cols:                          # all cross-attention K/V projections in one GEMM; layers take column slices
             ehs_act = self.linear(ehs_act, "attn2_kv_all")
             ehs_act.rg = train
+            if self.attn_fp8:        # the K / V of every cross attention, once
+                k.quantize_e4m3_(ehs_act.t)
         c0p = padc(c0)
         nskip = 0
 

@@ -64,7 +64,7 @@ class UNet2DConditionModelPruned:
     config_name = "config.json"
 
     def __init__(self, cfg: UNetConfig = None, arch_vector=None, device=None, dtype=torch.bfloat16, train=True,
-                 seed=0, init=True):
+                 seed=0, init=True, attention_precision=None):
         if not torch.cuda.is_available():
             raise RuntimeError("UNet2DConditionModelPruned (MI355X engine) needs a GPU; there is no CPU fallback")
         self.cfg = cfg or UNetConfig.sd21()
@@ -74,6 +74,7 @@ class UNet2DConditionModelPruned:
         self.blocks = apply_arch_vector(self.cfg, self.arch_vector)
         self.store = ParamStore(build_entries(self.cfg, self.blocks), self.device, dtype, train=train)
         self.engine = UNetEngine(self.cfg, self.blocks, self.store, dtype)
+        self.set_attention_precision(attention_precision)
         self.training = train
         n = len(self.cfg.block_out_channels)
         self.down_blocks = [_BlockHandle(f"down_blocks.{i}") for i in range(n)]
@@ -85,12 +86,24 @@ class UNet2DConditionModelPruned:
         if init:
             self.store.init_random(seed)
 
+    def set_attention_precision(self, precision):
+        """None / "bf16" / "fp32": attention operands in the activation dtype (the reference: F.scaled_dot_product_attention on what
+        the projections produce, blocks.py:257-277).  "fp8_e4m3" (BASELINE.json configs[4], PDMK_ATTN_FP8=1): Q, K and V are rounded to
+        the e4m3fn value grid before the attention kernels, forward and backward alike (pdmk_quantize_e4m3; straight-through for the
+        gradients of the projections)."""
+        if precision is None and os.environ.get("PDMK_ATTN_FP8") == "1":
+            precision = "fp8_e4m3"
+        if precision not in (None, "bf16", "fp32", "no", "fp8_e4m3"):
+            raise ValueError(f"attention_precision={precision!r}: expected None, 'fp8_e4m3' (or 'bf16' / 'fp32' = the activation dtype)")
+        self.attention_precision = precision
+        self.engine.attn_fp8 = precision == "fp8_e4m3"
+
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, subfolder=None, revision=None, arch_vector=None,
                         random_init=False, down_block_types=None, mid_block_type=None, up_block_types=None,
                         gated_ff=True, ff_gate_width=32, unet_config=None, torch_dtype=torch.bfloat16, device=None,
-                        train=True, seed=0, **unused):
+                        train=True, seed=0, attention_precision=None, **unused):
         cfg = unet_config or UNetConfig.sd21()
         _check_block_types(down_block_types, _GATED_DOWN, cfg.attn_stages_down, "down_block_types")
         _check_block_types(up_block_types, _GATED_UP, cfg.attn_stages_up, "up_block_types")
@@ -106,7 +119,8 @@ class UNet2DConditionModelPruned:
         have_local = bool(path) and os.path.isdir(path)
         if arch_vector is None and have_local and os.path.exists(os.path.join(path, "arch_vector.pt")):
             arch_vector = torch.load(os.path.join(path, "arch_vector.pt"), map_location="cpu")
-        model = cls(cfg, arch_vector, device, torch_dtype, train=train, seed=seed, init=random_init or not have_local)
+        model = cls(cfg, arch_vector, device, torch_dtype, train=train, seed=seed, init=random_init or not have_local,
+                    attention_precision=attention_precision)
         if have_local and not random_init:
             model.load_pretrained_dir(path)
         elif not random_init:

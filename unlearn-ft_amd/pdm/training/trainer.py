@@ -203,6 +203,7 @@ class Trainer:
         kw = dict(unet_config=ucfg, torch_dtype=self.weight_dtype, device=self.device,
                   down_block_types=pm.get("unet_down_blocks"), up_block_types=pm.get("unet_up_blocks"),
                   mid_block_type=pm.get("unet_mid_block"),
+                  attention_precision=pm.get("attention_precision", _cfg(c, "attention_precision")),
                   gated_ff=pm.get("gated_ff", True), ff_gate_width=pm.get("ff_gate_width", 32))
         self.teacher_model = UNet2DConditionModelPruned.from_pretrained(root if local else None, subfolder="unet",
                                                                         arch_vector=None, random_init=not local,
