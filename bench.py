@@ -245,7 +245,8 @@ def main():
     def warm():
         nonlocal graphs
         if use_graph:              # (--no_graph: plans are made by the untimed warm-up iterations, rank by rank)
-            graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
+            graphs = GraphedBilevel(st, B, 4, a.latent, a.latent, T, cfg.cross_attention_dim,
+                                    prefetch=os.environ.get("PDMK_TEACHER_PREFETCH", "1") != "0")
             graphs.capture(bilevel=True)
 
     if world > 1 and use_graph:
@@ -265,14 +266,20 @@ def main():
     else:
         warm()
 
-    def bilevel_iter(i):
-        d, u = data[i % nb], data[(i + 1) % nb]
+    tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
+
+    def bilevel_iter(i, base=0):
+        """i: iteration of the loop it is called from (upper-step cadence); base + i names the batch (prefetch tokens run on from
+        the warm-up loop into the timed one)."""
+        d, u = data[(base + i) % nb], data[(base + i + 1) % nb]
         if graphs is None:
             main_iter(i)
             if (i + 1) % a.upper_freq == 0:
                 upper_iter(i)
         else:
-            graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
+            # (prefetch mode, GraphedBilevel.prefetch: the next main batch is announced, as a dataloader one batch ahead would;
+            # every timed iteration still holds exactly one teacher pass - the one of the following batch)
+            graphs.main(*tup(d), batch_id=base + i, next_batch=tup(u), next_id=base + i + 1)
             if (i + 1) % a.upper_freq == 0:
                 graphs.upper(u["lat"], u["noise"], u["t"], u["ehs"], empty)
 
@@ -288,7 +295,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        bilevel_iter(i)
+        bilevel_iter(i, a.warmup)
     sync()
     el = time.perf_counter() - t0
     if world > 1:
@@ -309,13 +316,14 @@ def main():
         if world == 1:
             if graphs is not None:
                 d0 = data[0]
-                tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
-                extras["ms_main_step"] = round(timed(lambda j: graphs.main(*tup(data[j % nb])), 4) * 1e3, 2)
+                extras["ms_main_step"] = round(timed(lambda j: graphs.main(*tup(data[j % nb]), batch_id=("x", j), next_batch=tup(data[(j + 1) % nb]),
+                                                                           next_id=("x", j + 1)), 4) * 1e3, 2)
                 extras["ms_upper_step"] = round(timed(lambda j: graphs.upper(d0["lat"], d0["noise"], d0["t"], d0["ehs"], empty), 2) * 1e3, 2)
                 st.defer_reduce = False
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
+        extras["teacher_prefetch"] = bool(graphs is not None and graphs.prefetch)    # GraphedBilevel: teacher pass of batch t+1 beside step t's backward
         if graphs is not None:
             extras["graphs_per_main_step"] = len(graphs.g_main.all())
         extras["lockstep_forward"] = bool(st.lockstep)
@@ -535,6 +543,9 @@ def main():
                           "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if world > 1 else "none",
                           "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else 0),
                           "dp_mode": st.reducer.mode + ("/native-comm" if st.reducer.comm is not None else ""),
+                          # one batch of look-ahead: the frozen teacher's pass over batch t+1 runs beside step t's backward; every
+                          # timed iteration holds exactly one teacher pass (Trainer: training.teacher_prefetch)
+                          "teacher_prefetch": bool(graphs is not None and graphs.prefetch),
                           "curve_note": "the shipped bilevel YAML runs B=16/GPU: the N=1 point of THAT curve is extras.b16 "
                                         "(N>1: rerun with --batch 16); `value` is configs[1]'s B=8/GPU"},
                "roofline": roof, "cpu_baseline": cpu, "extras": extras}

@@ -345,6 +345,44 @@ def test_graph_replay_with_teacher_graph_matches_eager_and_survives_recapture(de
         x.close()
 
 
+def test_teacher_prefetch_gives_the_plain_graph_replay(dev):
+    """Cross-step teacher prefetch (GraphedBilevel(prefetch=True)): the frozen teacher's pass over batch t+1 is replayed on the
+    teacher stream behind the loss heads of step t, from the teacher graph's OWN static inputs.  Six bilevel iterations over four
+    batches (upper step after the second and the fifth; the fourth main step is NOT announced, the fifth is announced under a
+    token the caller then does not present: both run their teacher in line) must give the losses and parameters of the plain
+    replay; the hand-over is counted."""
+    from pdm.training.bilevel import BilevelStepper, GraphedBilevel
+    g = torch.Generator().manual_seed(11)
+    batches = [tuple(x.cuda() for x in (torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g),
+                                        torch.randint(0, 1000, (2,), generator=g), torch.randn(2, 13, 64, generator=g)))
+               for _ in range(4)]
+    empty = torch.randn(1, 13, 64, generator=g).expand(2, 13, 64).contiguous().cuda()
+    results = []
+    for pre in (False, True):
+        ocfg, dense, psd, info, student, teacher = _setup(torch.float32)
+        st = BilevelStepper(student, teacher, lr=1e-4, upper_lr=1e-4, bilevel=True)
+        gr = GraphedBilevel(st, 2, 4, 16, 16, 13, 64, segments=3, prefetch=pre)
+        gr.capture(bilevel=True)
+        assert gr.prefetch == pre
+        losses = []
+        for i in range(6):
+            b, nb_ = batches[i % 4], batches[(i + 1) % 4]
+            announce = i != 2                                  # step 3 finds nothing queued for it
+            token = i if i != 5 else "someone else's"          # ... and step 5 a pass queued under another name
+            gr.main(*b, batch_id=token, next_batch=nb_ if announce else None, next_id=i + 1)
+            losses.append(st.losses.clone())
+            if i in (1, 4):
+                gr.upper(*b, empty)
+                losses.append(st.losses.clone())
+        torch.cuda.synchronize()
+        assert gr.prefetch_hits == (3 if pre else 0), gr.prefetch_hits      # steps 1, 2 and 4
+        results.append((torch.stack(losses).cpu(), student.store.master.clone()))
+        gr.close()
+    assert torch.allclose(results[1][0], results[0][0], rtol=1e-5, atol=1e-9), (results[1][0], results[0][0])
+    d, dr = (results[1][1] - results[0][1]).abs().max().item(), results[0][1].abs().max().item()
+    assert d <= 1e-5 * dr + 8e-4, d          # Adam turns round-off-sized gradients into +-lr steps (see the DP test)
+
+
 @pytest.mark.parametrize("dn,tol", [("f32", 1e-3), ("bf16", 2e-2)])
 def test_bilevel_loss_curve_matches_oracle(dev, dn, tol):
     """north_star: "loss curves matching the CPU reference to 1e-3".  Nine bilevel iterations on the tiny topology - main

@@ -123,23 +123,33 @@ def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
     (DESIGN.md 2)."""
     from pdm.training.trainer import BilevelUnetFineTuner
     runs = []
-    for mode in (False, True):
-        cfg = _config(tmp_path / ("g" if mode else "e"), 6)
+    # third run: `training.teacher_prefetch` - train() looks one batch ahead and the teacher's pass over batch t+1 runs beside step
+    # t's backward; the draws keep the eager order (main t, upper t, main t+1), so it is the same curve again, and the generator
+    # state a checkpoint stores is the one BEFORE the look-ahead draw (checkpoint-4 is written with batch 4 already drawn)
+    for name, mode, pre in (("e", False, False), ("g", True, False), ("p", True, True)):
+        cfg = _config(tmp_path / name, 6)
         cfg["training"]["hip_graphs"] = mode
+        cfg["training"]["teacher_prefetch"] = pre
         tr = BilevelUnetFineTuner(cfg)
         tr.train()
-        recs = [json.loads(l) for l in open(tmp_path / ("g" if mode else "e") / "metrics.jsonl")]
+        recs = [json.loads(l) for l in open(tmp_path / name / "metrics.jsonl")]
         runs.append((recs, tr.prediction_model.store.master.clone(), tr.stepper.opt.t, tr.stepper.upper_opt.t))
         if mode:
             assert len(tr._graphs) == 1
-    (re, we, te, ue), (rg, wg, tg, ug) = runs
-    assert (te, ue) == (tg, ug) == (6, 2) and len(re) == len(rg) == 6
-    assert [sorted(r) for r in re] == [sorted(r) for r in rg]
-    for a, b in zip(re, rg):
-        for key in a:
-            assert abs(a[key] - b[key]) <= 2e-2 * abs(a[key]) + 1e-7, (key, a[key], b[key])
-    d = (we - wg).abs()
-    assert d.max().item() <= 5e-3 and d.mean().item() <= 2e-3 * we.abs().mean().item() + 1e-6, (d.max().item(), d.mean().item())
+            assert next(iter(tr._graphs.values())).prefetch_hits == (5 if pre else 0)      # steps 1 .. 5
+    (re, we, te, ue) = runs[0]
+    for (rg, wg, tg, ug) in runs[1:]:
+        assert (te, ue) == (tg, ug) == (6, 2) and len(re) == len(rg) == 6
+        assert [sorted(r) for r in re] == [sorted(r) for r in rg]
+        for a, b in zip(re, rg):
+            for key in a:
+                assert abs(a[key] - b[key]) <= 2e-2 * abs(a[key]) + 1e-7, (key, a[key], b[key])
+        d = (we - wg).abs()
+        assert d.max().item() <= 5e-3 and d.mean().item() <= 2e-3 * we.abs().mean().item() + 1e-6, (d.max().item(), d.mean().item())
+    import pickle
+    states = [pickle.load(open(tmp_path / name / "checkpoint-4" / "random_states_0.pkl", "rb"))["pdm_generator_state"]
+              for name in ("g", "p")]
+    assert torch.equal(states[0], states[1])
 
 
 def test_hip_graph_mode_keeps_one_capture_per_batch_shape(dev, tmp_path):

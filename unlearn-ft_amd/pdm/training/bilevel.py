@@ -568,7 +568,7 @@ class GraphedBilevel:
        with max_streams == 1 never enter that code.  Inputs are copied into static buffers; lr / bias corrections live in
        device scalars updated outside the graphs."""
 
-    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True):
+    def __init__(self, stepper, B, C, H, W, T, ctx, segments=6, stream_opt=True, prefetch=None):
         self.st = stepper
         dev = stepper.dev
         self.shape = (B, C, H, W, T, ctx)
@@ -586,11 +586,29 @@ class GraphedBilevel:
         self.opt_stream = k.role_stream(dev, "opt")
         self.cap_stream = k.role_stream(dev, "capture")
         self.closed = False
+        # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=1, or prefetch=True): the frozen teacher's pass over the NEXT main
+        # batch (`main(..., next_batch=, next_id=)`) is replayed on the teacher stream as soon as this step's loss heads have
+        # read the current outputs (behind bwd[0]), i.e. beside 5/6 of the backward, the AdamW and the next student forward,
+        # instead of beside the student forward alone.  The teacher graph then reads its OWN static inputs; a prefetched pass is
+        # only used when the caller names the batch again (`batch_id`), else the teacher runs in line as before.
+        self.prefetch = ((prefetch if prefetch is not None else os.environ.get("PDMK_TEACHER_PREFETCH", "0") == "1")
+                         and stepper.teacher_stream is not None and not stepper.lockstep and stepper.need_teacher)
+        self.t_in = ([torch.zeros_like(b) for b in (self.lat, self.noise, self.t, self.ehs)] if self.prefetch else None)
+        self._ahead = None                   # id of the batch whose teacher outputs are queued / done on the teacher stream
+        self.prefetch_hits = 0               # main steps that found their teacher pass queued (tests, bench extras)
+        # the backward graph behind which the next teacher pass is queued: 0 = as early as the data allow (the loss heads live in
+        # bwd[0]); later = the pass straddles the step boundary and its tail runs beside the next student forward
+        self.prefetch_at = int(os.environ.get("PDMK_PREFETCH_AT", "0"))
 
     def _load(self, lat, noise, t, ehs, empty=None):
         self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
         if empty is not None:
             self.empty.copy_(empty)
+
+    def _load_teacher(self, lat, noise, t, ehs):
+        """The main-step teacher graph's own static inputs (prefetch mode), copied on the CURRENT stream."""
+        for dst, src in zip(self.t_in, (lat, noise, t, ehs)):
+            dst.copy_(src)
 
     # ------------------------------------------------------------------ capture
     def capture(self, bilevel=True):
@@ -607,6 +625,8 @@ class GraphedBilevel:
         for buf in (self.lat, self.noise, self.ehs, self.empty):
             buf.normal_(generator=gen)
         self.t.random_(0, 1000, generator=gen)
+        if self.prefetch:
+            self._load_teacher(self.lat, self.noise, self.t, self.ehs)
         cap = self.cap_stream
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
@@ -665,8 +685,9 @@ class GraphedBilevel:
         try:
             with torch.cuda.stream(cap):
                 tout = None
+                tin = self.t_in if self.prefetch else (self.lat, self.noise, self.t, self.ehs)
                 tfwd = ((lambda: st.upper_teacher_pass(self.lat, self.noise, self.t, self.ehs, self.empty)) if upper else
-                        (lambda: st.teacher_pass(self.lat, self.noise, self.t, self.ehs)))
+                        (lambda: st.teacher_pass(*tin)))
                 sfwd = lambda: st.student_forward(self.lat, self.noise, self.t, self.ehs, train=True, want_target=not upper)
                 if need_t and not st.lockstep:             # teacher as its own graph, replayed on the teacher stream
                     cs.teacher = torch.cuda.CUDAGraph()
@@ -696,14 +717,28 @@ class GraphedBilevel:
         return cs
 
     # ------------------------------------------------------------------ replay
-    def _replay_step(self, cs, opt=None):
-        """opt: the optimiser to apply (None = gradients only, the caller applies the optimiser)."""
+    def _replay_step(self, cs, opt=None, have_teacher=False, ahead=None):
+        """opt: the optimiser to apply (None = gradients only, the caller applies the optimiser).
+        have_teacher: the teacher graph of this step is already queued on the teacher stream (prefetched by the previous step).
+        ahead: (lat, noise, t, ehs) of the NEXT main batch - its teacher pass is queued behind this step's first backward graph."""
         st = self.st
         store = st.student.store
         cur = torch.cuda.current_stream()
         side = st.teacher_stream is not None
         ts = st.teacher_stream if side else cur
-        if cs.teacher is not None:
+
+        def teacher_ahead(i):
+            if ahead is None or i != min(self.prefetch_at, len(cs.bwd) - 1):
+                return
+            ts.wait_stream(cur)                  # bwd[0] holds the loss heads: the current teacher outputs have been read
+            with torch.cuda.stream(ts):
+                for src in ahead:
+                    if src.is_cuda:
+                        src.record_stream(ts)
+                self._load_teacher(*ahead)
+                cs.teacher.replay()
+
+        if cs.teacher is not None and not have_teacher:
             if side:
                 ts.wait_stream(cur)              # inputs loaded; the previous step's loss heads have read the old outputs
             with torch.cuda.stream(ts):
@@ -717,8 +752,9 @@ class GraphedBilevel:
         streamed = opt is not None and self.stream_opt
         if st.world == 1:
             hi = store.total
-            for g, off in zip(cs.bwd, cs.offs):
+            for i, (g, off) in enumerate(zip(cs.bwd, cs.offs)):
                 g.replay()
+                teacher_ahead(i)
                 if streamed and len(cs.bwd) > 1 and not self.force_segments:
                     self.opt_stream.wait_stream(cur)             # the share [off, hi) is final
                     with torch.cuda.stream(self.opt_stream):
@@ -733,8 +769,9 @@ class GraphedBilevel:
         red = st.reducer
         red.begin()
         done = store.total                       # AdamW has been issued for [done, total)
-        for g, off in zip(cs.bwd, cs.offs):
+        for i, (g, off) in enumerate(zip(cs.bwd, cs.offs)):
             g.replay()
+            teacher_ahead(i)
             red.ready_down_to(off)               # comm stream waits for the graph just queued, then reduces its whole buckets
             if streamed and red.stream is not None and red.next_hi < done:
                 with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind them
@@ -745,11 +782,22 @@ class GraphedBilevel:
             opt.launch_range(0, done, st._gscale)
             store.refresh(w_is_fresh=fresh, wt=not store.defer_wt)
 
-    def main(self, lat, noise, t, ehs):
-        """One main step + its AdamW."""
+    def main(self, lat, noise, t, ehs, batch_id=None, next_batch=None, next_id=None):
+        """One main step + its AdamW.  Prefetch mode: `next_batch` = (lat, noise, t, ehs) of the following main step, `next_id`
+        a token for it; the call that passes the same token as `batch_id` finds its teacher outputs already queued."""
         lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches of the step
         self._load(lat, noise, t, ehs)
-        self._replay_step(self.g_main, self.st.opt)
+        have = self.prefetch and batch_id is not None and self._ahead == batch_id
+        self.prefetch_hits += int(have)
+        if self.prefetch and not have:
+            if self._ahead is not None and self.st.teacher_stream is not None:     # a prefetched pass nobody asked for again
+                torch.cuda.current_stream().wait_stream(self.st.teacher_stream)    # is still reading the teacher's inputs
+            self._load_teacher(lat, noise, t, ehs)
+        ahead = next_batch if (self.prefetch and next_batch is not None and next_id is not None) else None
+        self._ahead = None
+        self._replay_step(self.g_main, self.st.opt, have_teacher=have, ahead=ahead)
+        if ahead is not None:
+            self._ahead = next_id
         if not self.stream_opt:
             self.st.opt.launch(self.st._gscale)
         return lr

@@ -90,6 +90,11 @@ class Trainer:
         # at most `training.hip_graph_shapes` (default 3) stay alive, the least recently used one is closed at an idle point
         self._graphs = {}
         self._graph_lr = {}
+        # `training.teacher_prefetch: true` (graph mode only; what bench.py measures): train() looks one batch ahead and the frozen
+        # teacher's pass over batch t+1 runs beside the backward / AdamW of step t (GraphedBilevel.main(next_batch=)).  The random
+        # draws keep the eager order (main t, upper t, main t+1, ...): the loss curve is the eager trainer's.
+        self.teacher_prefetch = self.hip_graphs and bool(_cfg(config, "training.teacher_prefetch", _cfg(config, "teacher_prefetch", False)))
+        self._rng_snapshot = None            # generator state a checkpoint must store while a look-ahead draw is outstanding
         if self.hip_graphs:
             pert = float(_cfg(config, "model.prediction_model.input_perturbation", 0.0) or 0.0)
             if self.max_grad_norm is not None or pert:
@@ -297,16 +302,28 @@ class Trainer:
             while len(self._graphs) >= keep:                 # evict the least recently used shape: ordered teardown, device idle
                 self._graphs.pop(next(iter(self._graphs))).close()
             B, C, H, W = lat.shape
-            g = GraphedBilevel(self.stepper, B, C, H, W, ehs.shape[1], ehs.shape[2])
+            g = GraphedBilevel(self.stepper, B, C, H, W, ehs.shape[1], ehs.shape[2], prefetch=self.teacher_prefetch)
             g.capture(bilevel=self.bilevel)
         self._graphs[key] = g                                # most recently used last
         return g
 
-    def step(self, batch, backward=True):
+    def _prepare(self, batch, upper=False):
+        """The host-visible prologue of step() / upper_step(): every random draw of the step and its prompt embeddings."""
         lat, noise, t = self._sample(batch)
+        if upper and self._input_noise is not None:      # trainer.py:2917-2932: the upper step diffuses with the perturbed noise
+            noise = self._input_noise
         ehs = self._prompt_embeds(batch)
+        return (lat, noise, t, ehs, self._prompt_embeds(batch, empty=True)) if upper else (lat, noise, t, ehs)
+
+    def step(self, batch, backward=True, prepared=None, ahead=None, ids=(None, None)):
+        """prepared: `_prepare(batch)` done earlier (look-ahead); ahead: the prepared NEXT main batch, announced to the graphs
+        under the token ids[1] - the call that then passes it as `prepared` with ids[0] == that token finds its teacher pass done."""
+        lat, noise, t, ehs = prepared if prepared is not None else self._prepare(batch)
         if backward and self.hip_graphs:          # graph replay: loss heads + backward + all-reduce + AdamW in one go
-            self._graph_lr["main"] = self._graphed(lat, ehs).main(lat, noise, t, ehs)
+            if ahead is not None and not (ahead[0].shape == lat.shape and ahead[3].shape == ehs.shape):
+                ahead = None                       # another batch shape has its own graphs: no hand-over between them
+            self._graph_lr["main"] = self._graphed(lat, ehs).main(lat, noise, t, ehs, batch_id=ids[0], next_batch=ahead,
+                                                                  next_id=ids[1])
             return self._tuple(self.stepper.losses.clone(), upper=False)
         L = self.stepper.main_step(lat, noise, t, ehs, backward=backward, input_noise=self._input_noise)
         return self._tuple(L, upper=False)
@@ -390,7 +407,8 @@ class Trainer:
         import numpy as np
         rng = {"step": self.global_step, "random_state": random.getstate(), "numpy_random_seed": np.random.get_state(),
                "torch_manual_seed": torch.get_rng_state(), "torch_cuda_manual_seed": torch.cuda.get_rng_state_all(),
-               "pdm_generator_state": self.rng.get_state().cpu()}        # this build draws from its own device generator
+               # this build draws from its own device generator (with a look-ahead batch drawn: its state BEFORE that draw)
+               "pdm_generator_state": (self._rng_snapshot if self._rng_snapshot is not None else self.rng.get_state()).cpu()}
         with open(os.path.join(d, f"random_states_{self.rank}.pkl"), "wb") as f:       # every rank writes its own
             pickle.dump(rng, f)
         if self.rank != 0:
@@ -478,28 +496,59 @@ class UnetFineTuner(Trainer):
         pending = None
         t0 = time.time()
         epoch = first_epoch
+        log_every = int(_cfg(c, "training.image_logging_steps", 0) or 0)
+        ahead = None                # (prepared next main batch, its token) - teacher_prefetch only
         # for epoch in range(first_epoch, num_train_epochs) (trainer.py:2769)
         while self.global_step < max_steps and (epochs is None or epoch < epochs):
             stepped = False
-            for batch in self.train_dataloader:
+            it = iter(self.train_dataloader)
+            nxt = next(it, None)
+            while nxt is not None:
+                batch, nxt = nxt, next(it, None)
                 if self.global_step >= max_steps:
                     break
                 if self._is_empty(batch):                        # empty batch is skipped (trainer.py:2771-2772)
                     continue
                 stepped = True
-                loss = self.step(batch)
+                upper_due = self.bilevel and (self.global_step + 1) % freq == 0
+                ub = up_prepared = None
+                if self.teacher_prefetch:
+                    # every draw in the eager order - this batch (drawn one step ago, or now), then the upper batch that follows
+                    # it, then the look-ahead - before anything is launched
+                    gs = self.global_step
+                    prepared = ahead[0] if (ahead is not None and ahead[1] == gs) else self._prepare(batch)
+                    ahead, self._rng_snapshot = None, None
+                    if upper_due:
+                        try:
+                            ub = next(upper_iter)
+                        except StopIteration:
+                            upper_iter = iter(self.upper_dataloader)
+                            ub = next(upper_iter)
+                        up_prepared = self._prepare(ub, upper=True)
+                    # no look-ahead into a step that will not run, across an epoch boundary, or past a point where something else
+                    # draws from the generator / stores its state between the steps (validation, image logging)
+                    quiet = not (val_every and gs % val_every == 0) and not (log_every and self.prompt_dataloader is not None
+                                                                             and gs % log_every == 0)
+                    if nxt is not None and not self._is_empty(nxt) and gs + 1 < max_steps and quiet:
+                        self._rng_snapshot = self.rng.get_state()
+                        ahead = (self._prepare(nxt), gs + 1)
+                    loss = self.step(batch, prepared=prepared, ahead=ahead[0] if ahead else None,
+                                     ids=(gs, gs + 1 if ahead else None))
+                else:
+                    loss = self.step(batch)
                 lr = (self._graph_lr["main"] if self.hip_graphs else
                       self.stepper.optimizer_step(upper=False, max_grad_norm=self.max_grad_norm))
                 rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
                 keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
                 vals = [torch.stack(loss)]
-                if self.bilevel and (self.global_step + 1) % freq == 0:          # trainer.py:2795-2816
-                    try:
-                        ub = next(upper_iter)
-                    except StopIteration:
-                        upper_iter = iter(self.upper_dataloader)
-                        ub = next(upper_iter)
-                    up = self.upper_step(ub)
+                if upper_due:          # trainer.py:2795-2816
+                    if ub is None:
+                        try:
+                            ub = next(upper_iter)
+                        except StopIteration:
+                            upper_iter = iter(self.upper_dataloader)
+                            ub = next(upper_iter)
+                    up = self.upper_step(ub, prepared=up_prepared)
                     rec["finetuning/upper_prediction_model_lr"] = (
                         self._graph_lr["upper"] if self.hip_graphs else
                         self.stepper.optimizer_step(upper=True, max_grad_norm=self.max_grad_norm))
@@ -513,7 +562,6 @@ class UnetFineTuner(Trainer):
                 pending[3].record()
                 if val_every and self.global_step % val_every == 0:        # trainer.py:2848-2850
                     self.validate()
-                log_every = int(_cfg(c, "training.image_logging_steps", 0) or 0)
                 if log_every and self.prompt_dataloader is not None and self.global_step % log_every == 0:
                     self.generate_samples_from_prompts()
                 self.global_step += 1
@@ -542,11 +590,8 @@ class BilevelUnetFineTuner(UnetFineTuner):
     """Bilevel fine-tune + concept suppression (trainer.py:2577-3001)."""
     bilevel = True
 
-    def upper_step(self, batch):
-        lat, noise, t = self._sample(batch)
-        if self._input_noise is not None:          # trainer.py:2917-2932: the upper step diffuses with the perturbed noise
-            noise = self._input_noise
-        ehs, empty = self._prompt_embeds(batch), self._prompt_embeds(batch, empty=True)
+    def upper_step(self, batch, prepared=None):
+        lat, noise, t, ehs, empty = prepared if prepared is not None else self._prepare(batch, upper=True)
         if self.hip_graphs:
             self._graph_lr["upper"] = self._graphed(lat, ehs).upper(lat, noise, t, ehs, empty)
             return self._tuple(self.stepper.losses.clone(), upper=True)

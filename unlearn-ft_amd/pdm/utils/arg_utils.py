@@ -37,6 +37,8 @@ def parse_args(argv=None):
     p.add_argument("--keep_ratio", type=float, default=0.55, help="MAC budget of the random arch vector in synthetic mode")
     p.add_argument("--tiny", action="store_true", help="tiny U-Net topology (tests / smoke)")
     p.add_argument("--hip_graphs", action="store_true", help="replay the training step as captured hipGraphs (fixed batch shapes)")
+    p.add_argument("--teacher_prefetch", action="store_true",
+                   help="with --hip_graphs: look one batch ahead, the frozen teacher's pass over it runs beside this step's backward")
     args = p.parse_args(argv)
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
     if env_local_rank != -1 and env_local_rank != args.local_rank:
