@@ -347,10 +347,11 @@ def test_graph_replay_with_teacher_graph_matches_eager_and_survives_recapture(de
 
 def test_teacher_prefetch_gives_the_plain_graph_replay(dev):
     """Cross-step teacher prefetch (GraphedBilevel(prefetch=True)): the frozen teacher's pass over batch t+1 is replayed on the
-    teacher stream behind the loss heads of step t, from the teacher graph's OWN static inputs.  Six bilevel iterations over four
-    batches (upper step after the second and the fifth; the fourth main step is NOT announced, the fifth is announced under a
-    token the caller then does not present: both run their teacher in line) must give the losses and parameters of the plain
-    replay; the hand-over is counted."""
+    teacher stream behind the loss heads of step t (a graph of their own in this mode), from the teacher graph's OWN static inputs;
+    an upper step's 2B teacher pass is announced to the main step in front of it.  Six bilevel iterations over four batches (upper
+    step after the second and the fifth; the fourth main step is NOT announced, the sixth is announced under a token the caller then
+    does not present: both run their teacher in line) must give the losses and parameters of the plain replay; the hand-overs are
+    counted."""
     from pdm.training.bilevel import BilevelStepper, GraphedBilevel
     g = torch.Generator().manual_seed(11)
     batches = [tuple(x.cuda() for x in (torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 4, 16, 16, generator=g),
@@ -367,15 +368,18 @@ def test_teacher_prefetch_gives_the_plain_graph_replay(dev):
         losses = []
         for i in range(6):
             b, nb_ = batches[i % 4], batches[(i + 1) % 4]
-            announce = i != 2                                  # step 3 finds nothing queued for it
-            token = i if i != 5 else "someone else's"          # ... and step 5 a pass queued under another name
-            gr.main(*b, batch_id=token, next_batch=nb_ if announce else None, next_id=i + 1)
-            losses.append(st.losses.clone())
-            if i in (1, 4):
-                gr.upper(*b, empty)
+            token = i if i != 5 else "someone else's"          # step 5 finds a pass queued under another name ...
+            nxt = dict(next_batch=nb_, next_id=i + 1) if i != 2 else {}        # ... and step 3 nothing queued for it
+            if i in (1, 4):          # an upper step follows: ITS teacher pass is announced to the main step, the next main batch to it
+                gr.main(*b, batch_id=token, next_upper=b + (empty,), upper_id=("u", i))
                 losses.append(st.losses.clone())
+                gr.upper(*b, empty, batch_id=("u", i), **nxt)
+            else:
+                gr.main(*b, batch_id=token, **nxt)
+            losses.append(st.losses.clone())
         torch.cuda.synchronize()
-        assert gr.prefetch_hits == (3 if pre else 0), gr.prefetch_hits      # steps 1, 2 and 4
+        assert gr.prefetch_hits == (5 if pre else 0), gr.prefetch_hits      # main steps 1, 2 and 4, both upper steps
+        assert (gr.g_main.loss is not None) == pre and (gr.g_upper.loss is not None) == pre
         results.append((torch.stack(losses).cpu(), student.store.master.clone()))
         gr.close()
     assert torch.allclose(results[1][0], results[0][0], rtol=1e-5, atol=1e-9), (results[1][0], results[0][0])

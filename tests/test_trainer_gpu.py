@@ -136,7 +136,7 @@ def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
         runs.append((recs, tr.prediction_model.store.master.clone(), tr.stepper.opt.t, tr.stepper.upper_opt.t))
         if mode:
             assert len(tr._graphs) == 1
-            assert next(iter(tr._graphs.values())).prefetch_hits == (5 if pre else 0)      # steps 1 .. 5
+            assert next(iter(tr._graphs.values())).prefetch_hits == (7 if pre else 0)      # main steps 1 .. 5, upper steps 2 and 5
     (re, we, te, ue) = runs[0]
     for (rg, wg, tg, ug) in runs[1:]:
         assert (te, ue) == (tg, ug) == (6, 2) and len(re) == len(rg) == 6

@@ -547,10 +547,11 @@ class BilevelStepper:
 class _CapturedStep:
     """The hipGraphs of one step kind: teacher (own memory pool: it runs beside `fwd`), fwd, and the loss heads + backward
     cut into `len(bwd)` graphs; offs[i] = arena offset from which every gradient is final once bwd[i] has run."""
-    __slots__ = ("teacher", "fwd", "bwd", "offs", "keep")
+    __slots__ = ("teacher", "fwd", "loss", "bwd", "offs", "keep")
 
     def all(self):
-        return ([self.teacher] if self.teacher is not None else []) + [self.fwd] + list(self.bwd)
+        return (([self.teacher] if self.teacher is not None else []) + [self.fwd] +
+                ([self.loss] if self.loss is not None else []) + list(self.bwd))
 
 
 class GraphedBilevel:
@@ -559,6 +560,8 @@ class GraphedBilevel:
          teacher  forward diffusion + frozen teacher forward          -> replayed on the teacher stream
          fwd      forward diffusion + student forward                 -> main stream
          bwd[i]   loss heads + the i-th share of the backward pass    -> main stream, after the teacher stream has joined
+                  (prefetch mode: the loss heads are a graph of their own, `loss`, so that the teacher's next pass - which
+                  overwrites the outputs they read - can be queued right behind them)
 
        and everything that runs beside something else (teacher pass, dgrad-copy refresh, the AdamW of a finished share of the
        gradient arena, with world > 1 the bucketed all-reduce in front of it) is ordered BETWEEN the graphs with stream
@@ -586,29 +589,54 @@ class GraphedBilevel:
         self.opt_stream = k.role_stream(dev, "opt")
         self.cap_stream = k.role_stream(dev, "capture")
         self.closed = False
-        # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=1, or prefetch=True): the frozen teacher's pass over the NEXT main
-        # batch (`main(..., next_batch=, next_id=)`) is replayed on the teacher stream as soon as this step's loss heads have
-        # read the current outputs (behind bwd[0]), i.e. beside 5/6 of the backward, the AdamW and the next student forward,
-        # instead of beside the student forward alone.  The teacher graph then reads its OWN static inputs; a prefetched pass is
-        # only used when the caller names the batch again (`batch_id`), else the teacher runs in line as before.
+        # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=1, or prefetch=True): the frozen teacher's pass of the NEXT step in
+        # program order - the following main batch (`next_batch=, next_id=`) or the upper step that follows this main step
+        # (`next_upper=, upper_id=`) - is replayed on the teacher stream as soon as this step's loss heads have read the current
+        # outputs, i.e. beside the whole backward, the AdamW and the next student forward, instead of beside its own student
+        # forward alone.  The teacher graphs then read their OWN static inputs; a prefetched pass is only used when the caller
+        # names the batch again (`batch_id`), else the teacher runs in line as before.  Measured (same box, B = 8):
+        # 185.6 -> 190.3 images/s with the main pass alone; queued behind later backward graphs it is worth less and less.
         self.prefetch = ((prefetch if prefetch is not None else os.environ.get("PDMK_TEACHER_PREFETCH", "0") == "1")
                          and stepper.teacher_stream is not None and not stepper.lockstep and stepper.need_teacher)
         self.t_in = ([torch.zeros_like(b) for b in (self.lat, self.noise, self.t, self.ehs)] if self.prefetch else None)
-        self._ahead = None                   # id of the batch whose teacher outputs are queued / done on the teacher stream
-        self.prefetch_hits = 0               # main steps that found their teacher pass queued (tests, bench extras)
-        # the backward graph behind which the next teacher pass is queued: 0 = as early as the data allow (the loss heads live in
-        # bwd[0]); later = the pass straddles the step boundary and its tail runs beside the next student forward
-        self.prefetch_at = int(os.environ.get("PDMK_PREFETCH_AT", "0"))
+        self.u_in = ([torch.zeros_like(b) for b in (self.lat, self.noise, self.t, self.ehs, self.empty)] if self.prefetch else None)
+        self._ahead = {"main": None, "upper": None}      # id of the batch whose teacher outputs are queued / done on the teacher stream
+        self.prefetch_hits = 0               # steps that found their teacher pass queued (tests, bench extras)
 
     def _load(self, lat, noise, t, ehs, empty=None):
         self.lat.copy_(lat); self.noise.copy_(noise); self.t.copy_(t); self.ehs.copy_(ehs)
         if empty is not None:
             self.empty.copy_(empty)
 
-    def _load_teacher(self, lat, noise, t, ehs):
-        """The main-step teacher graph's own static inputs (prefetch mode), copied on the CURRENT stream."""
-        for dst, src in zip(self.t_in, (lat, noise, t, ehs)):
+    def _load_teacher(self, upper, *srcs):
+        """The teacher graph's own static inputs (prefetch mode), copied on the CURRENT stream."""
+        for dst, src in zip(self.u_in if upper else self.t_in, srcs):
             dst.copy_(src)
+
+    def _queue_teacher(self, cs, upper, srcs, token):
+        """Queues the teacher pass of a LATER step (inputs `srcs`) on the teacher stream, behind everything queued on the current
+        stream so far - the loss heads that read the outputs it will overwrite."""
+        ts, cur = self.st.teacher_stream, torch.cuda.current_stream()
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            for src in srcs:
+                if src.is_cuda:
+                    src.record_stream(ts)
+            self._load_teacher(upper, *srcs)
+            cs.teacher.replay()
+        self._ahead["upper" if upper else "main"] = token
+
+    def _claim(self, upper, batch_id, srcs):
+        """True when the teacher pass of this step is already queued under `batch_id`; else its inputs are loaded for an in-line pass."""
+        kind = "upper" if upper else "main"
+        have = self.prefetch and batch_id is not None and self._ahead[kind] == batch_id
+        if self.prefetch and not have:
+            if self._ahead[kind] is not None:                        # a prefetched pass nobody asked for again is still reading
+                torch.cuda.current_stream().wait_stream(self.st.teacher_stream)      # the teacher's inputs
+            self._load_teacher(upper, *srcs)
+        self._ahead[kind] = None
+        self.prefetch_hits += int(have)
+        return have
 
     # ------------------------------------------------------------------ capture
     def capture(self, bilevel=True):
@@ -626,7 +654,8 @@ class GraphedBilevel:
             buf.normal_(generator=gen)
         self.t.random_(0, 1000, generator=gen)
         if self.prefetch:
-            self._load_teacher(self.lat, self.noise, self.t, self.ehs)
+            self._load_teacher(False, self.lat, self.noise, self.t, self.ehs)
+            self._load_teacher(True, self.lat, self.noise, self.t, self.ehs, self.empty)
         cap = self.cap_stream
         cap.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cap):
@@ -659,7 +688,7 @@ class GraphedBilevel:
         cuts = [total * (nseg - 1 - i) // nseg for i in range(nseg - 1)]      # descending arena offsets
         # (a small LAST share - the one whose AdamW nothing can hide - was measured: 43.3 vs 43.3 ms per main step, no gain)
         cs = _CapturedStep()
-        cs.teacher, cs.bwd, cs.offs, cs.keep = None, [], [], []
+        cs.teacher, cs.loss, cs.bwd, cs.offs, cs.keep = None, None, [], [], []
         need_t = upper or st.need_teacher
         cap = self.cap_stream
         state = {"n": 0}
@@ -685,9 +714,9 @@ class GraphedBilevel:
         try:
             with torch.cuda.stream(cap):
                 tout = None
-                tin = self.t_in if self.prefetch else (self.lat, self.noise, self.t, self.ehs)
-                tfwd = ((lambda: st.upper_teacher_pass(self.lat, self.noise, self.t, self.ehs, self.empty)) if upper else
-                        (lambda: st.teacher_pass(*tin)))
+                tin = ((self.u_in if upper else self.t_in) if self.prefetch else
+                       (self.lat, self.noise, self.t, self.ehs) + ((self.empty,) if upper else ()))
+                tfwd = (lambda: st.upper_teacher_pass(*tin)) if upper else (lambda: st.teacher_pass(*tin))
                 sfwd = lambda: st.student_forward(self.lat, self.noise, self.t, self.ehs, train=True, want_target=not upper)
                 if need_t and not st.lockstep:             # teacher as its own graph, replayed on the teacher stream
                     cs.teacher = torch.cuda.CUDAGraph()
@@ -701,9 +730,16 @@ class GraphedBilevel:
                 else:
                     ctx = sfwd()
                 cs.fwd.capture_end()
+                heads = st.upper_loss_heads if upper else st.main_loss_heads
+                if self.prefetch and cs.teacher is not None:          # the loss heads as a graph of their own (class docstring)
+                    cs.loss = torch.cuda.CUDAGraph()
+                    cs.loss.capture_begin(pool=cs.fwd.pool(), capture_error_mode="thread_local")
+                    heads(ctx, tout, True)
+                    cs.loss.capture_end()
                 cs.bwd.append(torch.cuda.CUDAGraph())
                 cs.bwd[-1].capture_begin(pool=cs.fwd.pool(), capture_error_mode="thread_local")
-                (st.upper_loss_heads if upper else st.main_loss_heads)(ctx, tout, True)
+                if cs.loss is None:
+                    heads(ctx, tout, True)
                 st._gscale = st.backward()
                 cs.bwd[-1].capture_end()
                 cs.offs.append(0)
@@ -720,23 +756,12 @@ class GraphedBilevel:
     def _replay_step(self, cs, opt=None, have_teacher=False, ahead=None):
         """opt: the optimiser to apply (None = gradients only, the caller applies the optimiser).
         have_teacher: the teacher graph of this step is already queued on the teacher stream (prefetched by the previous step).
-        ahead: (lat, noise, t, ehs) of the NEXT main batch - its teacher pass is queued behind this step's first backward graph."""
+        ahead: callable that queues the teacher pass(es) of later steps; called once this step's loss heads are queued."""
         st = self.st
         store = st.student.store
         cur = torch.cuda.current_stream()
         side = st.teacher_stream is not None
         ts = st.teacher_stream if side else cur
-
-        def teacher_ahead(i):
-            if ahead is None or i != min(self.prefetch_at, len(cs.bwd) - 1):
-                return
-            ts.wait_stream(cur)                  # bwd[0] holds the loss heads: the current teacher outputs have been read
-            with torch.cuda.stream(ts):
-                for src in ahead:
-                    if src.is_cuda:
-                        src.record_stream(ts)
-                self._load_teacher(*ahead)
-                cs.teacher.replay()
 
         if cs.teacher is not None and not have_teacher:
             if side:
@@ -748,13 +773,16 @@ class GraphedBilevel:
         if cs.teacher is not None and side:
             cur.wait_stream(ts)
         st.join_wt_refresh()
+        if cs.loss is not None:
+            cs.loss.replay()
+        if ahead is not None:
+            ahead()
         fresh = store.dtype == torch.bfloat16
         streamed = opt is not None and self.stream_opt
         if st.world == 1:
             hi = store.total
-            for i, (g, off) in enumerate(zip(cs.bwd, cs.offs)):
+            for g, off in zip(cs.bwd, cs.offs):
                 g.replay()
-                teacher_ahead(i)
                 if streamed and len(cs.bwd) > 1 and not self.force_segments:
                     self.opt_stream.wait_stream(cur)             # the share [off, hi) is final
                     with torch.cuda.stream(self.opt_stream):
@@ -769,9 +797,8 @@ class GraphedBilevel:
         red = st.reducer
         red.begin()
         done = store.total                       # AdamW has been issued for [done, total)
-        for i, (g, off) in enumerate(zip(cs.bwd, cs.offs)):
+        for g, off in zip(cs.bwd, cs.offs):
             g.replay()
-            teacher_ahead(i)
             red.ready_down_to(off)               # comm stream waits for the graph just queued, then reduces its whole buckets
             if streamed and red.stream is not None and red.next_hi < done:
                 with torch.cuda.stream(red.stream):      # ... and updates the reduced part behind them
@@ -782,30 +809,35 @@ class GraphedBilevel:
             opt.launch_range(0, done, st._gscale)
             store.refresh(w_is_fresh=fresh, wt=not store.defer_wt)
 
-    def main(self, lat, noise, t, ehs, batch_id=None, next_batch=None, next_id=None):
-        """One main step + its AdamW.  Prefetch mode: `next_batch` = (lat, noise, t, ehs) of the following main step, `next_id`
-        a token for it; the call that passes the same token as `batch_id` finds its teacher outputs already queued."""
+    def _ahead_fn(self, next_batch, next_id, next_upper=None, upper_id=None):
+        if not self.prefetch:
+            return None
+        jobs = []
+        if next_upper is not None and upper_id is not None and self.g_upper is not None:      # needed first: queued first
+            jobs.append((self.g_upper, True, tuple(next_upper), upper_id))
+        if next_batch is not None and next_id is not None:
+            jobs.append((self.g_main, False, tuple(next_batch), next_id))
+        if not jobs:
+            return None
+        return lambda: [self._queue_teacher(*j) for j in jobs]
+
+    def main(self, lat, noise, t, ehs, batch_id=None, next_batch=None, next_id=None, next_upper=None, upper_id=None):
+        """One main step + its AdamW.  Prefetch mode: `next_batch` = (lat, noise, t, ehs) of the following main step under the token
+        `next_id`, and / or `next_upper` = (lat, noise, t, ehs, empty) of the upper step that follows this one under `upper_id`; the
+        call that passes the same token as `batch_id` finds its teacher outputs already queued."""
         lr = self.st.opt.prepare()               # lr / bias corrections are read by the AdamW launches of the step
         self._load(lat, noise, t, ehs)
-        have = self.prefetch and batch_id is not None and self._ahead == batch_id
-        self.prefetch_hits += int(have)
-        if self.prefetch and not have:
-            if self._ahead is not None and self.st.teacher_stream is not None:     # a prefetched pass nobody asked for again
-                torch.cuda.current_stream().wait_stream(self.st.teacher_stream)    # is still reading the teacher's inputs
-            self._load_teacher(lat, noise, t, ehs)
-        ahead = next_batch if (self.prefetch and next_batch is not None and next_id is not None) else None
-        self._ahead = None
-        self._replay_step(self.g_main, self.st.opt, have_teacher=have, ahead=ahead)
-        if ahead is not None:
-            self._ahead = next_id
+        have = self._claim(False, batch_id, (lat, noise, t, ehs))
+        self._replay_step(self.g_main, self.st.opt, have_teacher=have, ahead=self._ahead_fn(next_batch, next_id, next_upper, upper_id))
         if not self.stream_opt:
             self.st.opt.launch(self.st._gscale)
         return lr
 
-    def upper(self, lat, noise, t, ehs, empty):
+    def upper(self, lat, noise, t, ehs, empty, batch_id=None, next_batch=None, next_id=None):
         lr = self.st.upper_opt.prepare()
         self._load(lat, noise, t, ehs, empty)
-        self._replay_step(self.g_upper, self.st.upper_opt)
+        have = self._claim(True, batch_id, (lat, noise, t, ehs, empty))
+        self._replay_step(self.g_upper, self.st.upper_opt, have_teacher=have, ahead=self._ahead_fn(next_batch, next_id))
         if not self.stream_opt:
             self.st.upper_opt.launch(self.st._gscale)
         return lr
@@ -824,6 +856,8 @@ class GraphedBilevel:
             for g in reversed(cs.bwd):
                 g.reset()
             cs.bwd = []
+            if cs.loss is not None:
+                cs.loss.reset()
             if cs.teacher is not None:
                 cs.teacher.reset()
             cs.fwd.reset()

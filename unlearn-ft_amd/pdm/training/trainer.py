@@ -315,15 +315,20 @@ class Trainer:
         ehs = self._prompt_embeds(batch)
         return (lat, noise, t, ehs, self._prompt_embeds(batch, empty=True)) if upper else (lat, noise, t, ehs)
 
-    def step(self, batch, backward=True, prepared=None, ahead=None, ids=(None, None)):
+    @staticmethod
+    def _same_graphs(a, lat, ehs):
+        """Another batch shape has its own captured graphs: no teacher hand-over between them."""
+        return a is not None and a[0].shape == lat.shape and a[3].shape == ehs.shape
+
+    def step(self, batch, backward=True, prepared=None, ahead=None, ids=(None, None), upper_ahead=None, upper_id=None):
         """prepared: `_prepare(batch)` done earlier (look-ahead); ahead: the prepared NEXT main batch, announced to the graphs
-        under the token ids[1] - the call that then passes it as `prepared` with ids[0] == that token finds its teacher pass done."""
+        under the token ids[1] - the call that then passes it as `prepared` with ids[0] == that token finds its teacher pass done;
+        upper_ahead / upper_id: the same for the upper step that follows this main step."""
         lat, noise, t, ehs = prepared if prepared is not None else self._prepare(batch)
         if backward and self.hip_graphs:          # graph replay: loss heads + backward + all-reduce + AdamW in one go
-            if ahead is not None and not (ahead[0].shape == lat.shape and ahead[3].shape == ehs.shape):
-                ahead = None                       # another batch shape has its own graphs: no hand-over between them
-            self._graph_lr["main"] = self._graphed(lat, ehs).main(lat, noise, t, ehs, batch_id=ids[0], next_batch=ahead,
-                                                                  next_id=ids[1])
+            self._graph_lr["main"] = self._graphed(lat, ehs).main(
+                lat, noise, t, ehs, batch_id=ids[0], next_batch=ahead if self._same_graphs(ahead, lat, ehs) else None, next_id=ids[1],
+                next_upper=upper_ahead if self._same_graphs(upper_ahead, lat, ehs) else None, upper_id=upper_id)
             return self._tuple(self.stepper.losses.clone(), upper=False)
         L = self.stepper.main_step(lat, noise, t, ehs, backward=backward, input_noise=self._input_noise)
         return self._tuple(L, upper=False)
@@ -532,8 +537,13 @@ class UnetFineTuner(Trainer):
                     if nxt is not None and not self._is_empty(nxt) and gs + 1 < max_steps and quiet:
                         self._rng_snapshot = self.rng.get_state()
                         ahead = (self._prepare(nxt), gs + 1)
-                    loss = self.step(batch, prepared=prepared, ahead=ahead[0] if ahead else None,
-                                     ids=(gs, gs + 1 if ahead else None))
+                    # each teacher pass gets the step in front of it as its window: the upper step's is announced to this main step,
+                    # the next main batch to the step that runs last in this iteration
+                    main_next = dict(ahead=ahead[0], next_id=gs + 1) if ahead else {}
+                    if upper_due:
+                        loss = self.step(batch, prepared=prepared, ids=(gs, None), upper_ahead=up_prepared, upper_id=("upper", gs))
+                    else:
+                        loss = self.step(batch, prepared=prepared, ahead=main_next.get("ahead"), ids=(gs, main_next.get("next_id")))
                 else:
                     loss = self.step(batch)
                 lr = (self._graph_lr["main"] if self.hip_graphs else
@@ -548,7 +558,8 @@ class UnetFineTuner(Trainer):
                         except StopIteration:
                             upper_iter = iter(self.upper_dataloader)
                             ub = next(upper_iter)
-                    up = self.upper_step(ub, prepared=up_prepared)
+                    up = (self.upper_step(ub, prepared=up_prepared, batch_id=("upper", self.global_step), **main_next)
+                          if self.teacher_prefetch else self.upper_step(ub))
                     rec["finetuning/upper_prediction_model_lr"] = (
                         self._graph_lr["upper"] if self.hip_graphs else
                         self.stepper.optimizer_step(upper=True, max_grad_norm=self.max_grad_norm))
@@ -590,10 +601,12 @@ class BilevelUnetFineTuner(UnetFineTuner):
     """Bilevel fine-tune + concept suppression (trainer.py:2577-3001)."""
     bilevel = True
 
-    def upper_step(self, batch, prepared=None):
+    def upper_step(self, batch, prepared=None, batch_id=None, ahead=None, next_id=None):
         lat, noise, t, ehs, empty = prepared if prepared is not None else self._prepare(batch, upper=True)
         if self.hip_graphs:
-            self._graph_lr["upper"] = self._graphed(lat, ehs).upper(lat, noise, t, ehs, empty)
+            self._graph_lr["upper"] = self._graphed(lat, ehs).upper(
+                lat, noise, t, ehs, empty, batch_id=batch_id, next_batch=ahead if self._same_graphs(ahead, lat, ehs) else None,
+                next_id=next_id)
             return self._tuple(self.stepper.losses.clone(), upper=True)
         L = self.stepper.upper_step(lat, noise, t, ehs, empty)
         return self._tuple(L, upper=True)
