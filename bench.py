@@ -267,6 +267,7 @@ def main():
         warm()
 
     tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
+    prefetch_on = bool(graphs is not None and graphs.prefetch)
 
     def bilevel_iter(i, base=0):
         """i: iteration of the loop it is called from (upper-step cadence); base + i names the batch (prefetch tokens run on from
@@ -331,7 +332,7 @@ def main():
             extras["ms_main_step_eager"] = round(timed(main_iter, 3) * 1e3, 2)
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
-        extras["teacher_prefetch"] = bool(graphs is not None and graphs.prefetch)    # GraphedBilevel: teacher pass of batch t+1 beside step t's backward
+        extras["teacher_prefetch"] = prefetch_on     # GraphedBilevel: teacher pass of batch t+1 beside step t's backward
         if graphs is not None:
             extras["graphs_per_main_step"] = len(graphs.g_main.all())
         extras["lockstep_forward"] = bool(st.lockstep)
@@ -498,6 +499,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_b16 and not a.tiny and B != 16 and graphs is not None:
         # the shipped bilevel YAML's per-GPU batch (configs/baselines/sd-2-1_coco_aptp_both_512_bilevel.yaml:48), same cadence,
         # same protocol, NOT the bench value (configs[1] is quoted at B = 8)
+        graphs.close()
         graphs = None
         torch.cuda.empty_cache()
         B2 = 16
@@ -506,20 +508,25 @@ def main():
                    t=torch.randint(0, 1000, (B2,), device=dev, generator=g),
                    ehs=torch.randn(B2, T, cfg.cross_attention_dim, device=dev, generator=g)) for _ in range(2)]
         e2 = empty[:1].expand(B2, -1, -1).contiguous()
-        g2 = GraphedBilevel(st, B2, 4, a.latent, a.latent, T, cfg.cross_attention_dim)
+        g2 = GraphedBilevel(st, B2, 4, a.latent, a.latent, T, cfg.cross_attention_dim,
+                            prefetch=os.environ.get("PDMK_TEACHER_PREFETCH", "1") != "0")
         g2.capture(bilevel=True)
 
-        def it2(i):
-            d = d2[i % 2]
-            g2.main(d["lat"], d["noise"], d["t"], d["ehs"])
+        def it2(i, base=0):          # the protocol of bilevel_iter above
+            d, u = d2[(base + i) % 2], d2[(base + i + 1) % 2]
+            nxt = dict(next_batch=tup(u), next_id=base + i + 1)
             if (i + 1) % a.upper_freq == 0:
-                g2.upper(d["lat"], d["noise"], d["t"], d["ehs"], e2)
+                ub = (d["lat"], d["noise"], d["t"], d["ehs"], e2)
+                g2.main(*tup(d), batch_id=base + i, next_upper=ub, upper_id=("u", base + i))
+                g2.upper(*ub, batch_id=("u", base + i), **nxt)
+            else:
+                g2.main(*tup(d), batch_id=base + i, **nxt)
         for i in range(2):
             it2(i)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(10):
-            it2(i)
+            it2(i, 2)
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t0
         extras["b16"] = {"images_per_s": round(10 * B2 / el2, 2), "ms_per_step": round(el2 / 10 * 1e3, 2), "batch": B2,
@@ -553,7 +560,7 @@ def main():
                           "dp_mode": st.reducer.mode + ("/native-comm" if st.reducer.comm is not None else ""),
                           # one batch of look-ahead: the frozen teacher's pass over batch t+1 runs beside step t's backward; every
                           # timed iteration holds exactly one teacher pass (Trainer: training.teacher_prefetch)
-                          "teacher_prefetch": bool(graphs is not None and graphs.prefetch),
+                          "teacher_prefetch": prefetch_on,
                           "curve_note": "the shipped bilevel YAML runs B=16/GPU: the N=1 point of THAT curve is extras.b16 "
                                         "(N>1: rerun with --batch 16); `value` is configs[1]'s B=8/GPU"},
                "roofline": roof, "cpu_baseline": cpu, "extras": extras}
