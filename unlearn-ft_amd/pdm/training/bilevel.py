@@ -581,7 +581,7 @@ class GraphedBilevel:
         self.ehs = torch.zeros(B, T, ctx, device=dev)
         self.empty = torch.zeros(B, T, ctx, device=dev)
         self.g_main = self.g_upper = None
-        self.segments = segments
+        self.segments = int(os.environ.get("PDMK_BWD_SEGMENTS", segments))      # (A/B knob: shares of the gradient arena = backward graphs)
         self.force_segments = False          # tests: cut the backward into segments on a single rank without streamed AdamW
         # AdamW of every finished share of the arena runs beside the rest of the backward (valid without gradient-norm
         # clipping, which needs all gradients first; the shipped configs do not clip: trainer.py:2784-2786)
