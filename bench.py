@@ -231,8 +231,8 @@ def main():
         st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], empty)
         st.optimizer_step(upper=True)
 
-    # hipGraph replay (immune to host jitter) on every rank count.  With N > 1 the backward is captured as 6 graphs cut at
-    # block boundaries of the tape, and the bucketed RCCL all-reduce of each finished sixth of the gradient arena is
+    # hipGraph replay (immune to host jitter) on every rank count.  With N > 1 the backward is captured as 12 graphs cut at
+    # block boundaries of the tape, and the bucketed RCCL all-reduce of each finished share of the gradient arena is
     # issued on the comm stream between the replays, i.e. it overlaps with the rest of the backward pass.
     # --no_graph: eager launches (all-reduce buckets issued from the backward tape).
     use_graph = not a.no_graph
