@@ -697,8 +697,7 @@ class GraphedBilevel:
 
         def seg_cb(off):
             if state["n"] < len(cuts) and off <= cuts[state["n"]]:
-                while state["n"] < len(cuts) and off <= cuts[state["n"]]:      # a block may span several shares: one cut for all
-                    state["n"] += 1
+                state["n"] += 1
                 st.student.engine.flush_pending()      # gradients in [off, total) are final only after this
                 cs.bwd[-1].capture_end()
                 cs.offs.append(off)
