@@ -30,6 +30,13 @@
                                   // a tap's two MFMA groups): measured 3-9 % SLOWER than 1 (64^2 320 -> 320: 71.2 -> 77.5 us), off
 #endif
 
+#ifndef PDMK_PRIO
+#define PDMK_PRIO 0               // wave priority experiments (MI355X_MICROARCH.md "Two waves per SIMD"): 1 = ONE s_setprio 1 for the second-dispatched
+                                  // half of the workgroup (waves 4-7) before the K-loop; 2 = s_setprio 1 / 0 around every MFMA cluster.
+                                  // Measured (round 4, ring + halo + weight-gradient bodies, same box, two builds): 193.4 images/s (0) vs 192.8 (1)
+                                  // vs 192.5 (2) - nothing to gain for these loops, OFF
+#endif
+
 namespace pdmk_ring {
 
 constexpr int BK = 64, NT = 512;
@@ -97,6 +104,11 @@ __device__ __forceinline__ int conv_src_pixel(const ConvGeom& g, int b, int oy, 
 }
 
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) { pdmk_wait_vmcnt(n); }   // n is wave-uniform
+__device__ __forceinline__ void prio_static(int wave) {       // wave is an SGPR value (readfirstlane): a scalar branch around one s_setprio
+    if (PDMK_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+}
+#define PDMK_PRIO_UP() do { if (PDMK_PRIO == 2) __builtin_amdgcn_s_setprio(1); } while (0)
+#define PDMK_PRIO_DOWN() do { if (PDMK_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
 
 // Epilogue shared by the ring kernels (same contract as gemm.hip): accumulators -> LDS staging image (64 rows per pass) ->
 // 16-byte rows of C with bias / rowvec / residual / accumulate fused, or fp32 atomics for split-K launches.
@@ -484,6 +496,7 @@ __device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigne
         if (kt0 + s < kt1) issue(s);
 
     int slot = 0;
+    prio_static(wave);
     for (int kt = kt0; kt < kt1; ++kt) {
         // younger K-steps already in flight: STAGES - 2 except in the last steps.  Immediate waits where the count is known at
         // compile time (always for the two-slot rings, in the steady state for the deep ones, per wave class): the computed
@@ -512,10 +525,12 @@ __device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigne
             for (int i = 0; i < IM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_row + fch + i * 2048);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
+            PDMK_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            PDMK_PRIO_DOWN();
             if (kk == 0 && late) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (kt + STAGES - 1 < kt1) issue(slot == 0 ? STAGES - 1 : slot - 1);
@@ -525,6 +540,7 @@ __device__ __forceinline__ void igemm_ring_body(const pdmk_gemm_args& g, unsigne
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
 
+    if (PDMK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     ring_epilogue<BM, NJ, STAGES * SLOT>(g, wgc, acc, smem, m0, n0);
 }
 
@@ -711,15 +727,18 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
             const unsigned fch = kk ? fch1 : fch0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row + fch + j * 2048);
+            PDMK_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            PDMK_PRIO_DOWN();
         }
         __builtin_amdgcn_sched_barrier(0);            // no cross-tap code motion: keeps fragment live ranges to one tap
     };
 
     const int nsteps = cb1 > cb0 ? (cb1 - cb0) * NTAPS : 0;
+    prio_static(wave);
     if (BSTAGES >= 4 && PDMK_HALO_PAIRS) {
         // ---- two taps per barrier (rings of >= 4 slots: the 128-row tiles).  A K-step of an 8-wave workgroup has ~480 cycles
         // of fixed cost (wait + barrier rendezvous + restart of the MFMA stream) next to 640 cycles of MFMA work
@@ -862,6 +881,7 @@ __device__ __forceinline__ void conv_halo_body(const pdmk_gemm_args& g, unsigned
     // zeros into LDS); the epilogue reuses that LDS as its staging image, so drain them explicitly - a late zero write
     // must not land on a staged tile, and what __syncthreads() happens to emit is not a contract
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (PDMK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
     if (NTAPS == 4 && !dgr) {
         if (tw == W) ring_epilogue<BM, NJ, 2 * P_BYTES + BSTAGES * B_BYTES, false, NTAPS == 4>(g, wgc, acc, smem, m0, n0);
@@ -1023,6 +1043,7 @@ __device__ __forceinline__ void wgrad_ring_body(const pdmk_gemm_args& g, int lg_
         if (kt0 + s < kt1) issue(kt0 + s, s);
 
     int slot = 0;
+    prio_static(wave);
     for (int kt = kt0; kt < kt1; ++kt) {
         if (STAGES == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (kt + STAGES - 1 <= kt1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (PA + PB)) : "memory");
@@ -1038,10 +1059,12 @@ __device__ __forceinline__ void wgrad_ring_body(const pdmk_gemm_args& g, int lg_
             for (int i = 0; i < IM; ++i) af[i] = tr_frag(sa, RA, kk, wm * (16 * IM) + i * 16);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bf[j] = tr_frag(sb, RB, kk, wn * (16 * NJ) + j * 16);
+            PDMK_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = MM::mma(bf[j], af[i], acc[i][j]);
+            PDMK_PRIO_DOWN();
             if (do_colsum) {
 #pragma unroll
                 for (int i = 0; i < IM; ++i) acs[i] = MM::mma(ones, af[i], acs[i]);
@@ -1049,6 +1072,7 @@ __device__ __forceinline__ void wgrad_ring_body(const pdmk_gemm_args& g, int lg_
         }
         slot = slot + 1 == STAGES ? 0 : slot + 1;
     }
+    if (PDMK_PRIO == 1) __builtin_amdgcn_s_setprio(0);
     if (do_colsum && (lane >> 4) == 0) {
 #pragma unroll
         for (int i = 0; i < IM; ++i) {
