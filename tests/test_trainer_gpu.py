@@ -114,6 +114,32 @@ def test_epochs_validation_and_input_perturbation(dev, tmp_path):
         UnetFineTuner(c2)
 
 
+def test_gradient_accumulation_steps_follow_the_reference_loops(dev, tmp_path):
+    """training.gradient_accumulation_steps = k as the reference's fine-tune loops treat it (trainer.py:2769-2800: no
+    `accelerator.accumulate` context, so the optimiser steps on every batch): every gradient is divided by k
+    (`accelerator.backward`), the logged finetuning/loss is loss / k, and an epoch counts ceil(len(dataloader) / k) update steps
+    when max_train_steps is derived from num_train_epochs (update_config_params, :445-450)."""
+    from pdm.training.trainer import BilevelUnetFineTuner
+    runs = []
+    for k_ in (1, 2):
+        cfg = _config(tmp_path / f"a{k_}", None)
+        cfg["training"]["gradient_accumulation_steps"] = k_
+        cfg["training"]["num_train_epochs"] = 1
+        tr = BilevelUnetFineTuner(cfg)
+        it = iter(tr.train_dataloader)
+        tr.train_dataloader = [next(it) for _ in range(4)]           # an epoch of 4 batches
+        tr.train()
+        recs = [json.loads(l) for l in open(tmp_path / f"a{k_}" / "metrics.jsonl")]
+        runs.append((tr.global_step, recs, tr.stepper._gscale, tr.prediction_model.store.master.clone()))
+    (s1, r1, g1, w1), (s2, r2, g2, w2) = runs
+    assert (s1, s2) == (4, 2) and (g1, g2) == (1.0, 0.5)               # 1 epoch = ceil(4 / k) optimiser steps; gradients / k
+    for a, b in zip(r1, r2):                                           # same batches, same draws: step 0 is the same forward
+        comp = b["finetuning/diffusion_loss"] + 2.0 * b["finetuning/distillation_loss"] + 0.1 * b["finetuning/block_loss"]
+        assert abs(b["finetuning/loss"] - comp / 2) <= 1e-5 * abs(comp) + 1e-7, (b, comp)
+    assert abs(r1[0]["finetuning/loss"] - 2 * r2[0]["finetuning/loss"]) <= 2e-2 * abs(r1[0]["finetuning/loss"])
+    assert torch.isfinite(w2).all() and not torch.equal(w1, w2)
+
+
 def test_hip_graph_mode_trains_like_eager_mode(dev, tmp_path):
     """`training.hip_graphs`: Trainer.train() replays the captured step (what bench.py measures) instead of eager launches;
     same seeded batches -> the same loss curve and the same final weights as the eager trainer (bf16 engine; split-K

@@ -285,6 +285,7 @@ class BilevelStepper:
         self.reducer = GradReducer(student.store, bucket_mb)
         self.reducer.flush_cb = student.engine.flush_pending
         self.defer_reduce = False
+        self.accum = 1                 # training.gradient_accumulation_steps: accelerate's backward divides every loss by it (Trainer.train)
         self.segment_cb = None
         self.in_graph = False          # GraphedBilevel: the pieces run under stream capture, on ONE stream
         # lockstep forward (PDMK_LOCKSTEP=1; OFF by default): the frozen teacher and the student run the same layer sequence
@@ -374,11 +375,11 @@ class BilevelStepper:
         if self.defer_reduce:          # graph mode: the all-reduce is issued by the caller between captured graphs
             self.student.engine.grad_ready_cb = self.segment_cb      # None, or GraphedBilevel's capture-segment switch
             self.student.engine.backward()
-            return 1.0 / self.world
+            return 1.0 / (self.world * self.accum)
         self.reducer.begin()
         self.student.engine.grad_ready_cb = self.reducer.ready_down_to
         self.student.engine.backward()
-        return self.reducer.finish()
+        return self.reducer.finish() / self.accum
 
     def reduce_now(self):
         self.reducer.begin()

@@ -476,13 +476,17 @@ class UnetFineTuner(Trainer):
         ck_every = int(_cfg(c, "training.logging.checkpoint_steps", _cfg(c, "training.checkpoint_steps", 10000)))
         val_every = int(_cfg(c, "training.validation_steps", 0) or 0)
         freq = int(_cfg(c, "training.upper_step_freq", 10))
-        accum = int(_cfg(c, "training.gradient_accumulation_steps", 1) or 1)
-        if accum != 1:
-            raise ValueError("gradient_accumulation_steps != 1 is not supported (every shipped config uses 1)")
+        # training.gradient_accumulation_steps = k, AS THE REFERENCE'S FINE-TUNE LOOPS TREAT IT (trainer.py:2293-2340, 2769-2800): they
+        # never enter `accelerator.accumulate(...)`, so `sync_gradients` stays True and the optimiser steps on EVERY batch; what k
+        # changes is (a) `accelerator.backward(loss)` divides the loss - i.e. every gradient, of the upper step too - by k,
+        # (b) the logged `finetuning/loss` is loss / k (:2778-2779), (c) an epoch counts ceil(len(dataloader) / k) update steps in
+        # update_config_params / update_train_steps / load_checkpoint (:445-450, 529-537, 508), (d) scale_lr (init_optimizer).
+        accum = max(1, int(_cfg(c, "training.gradient_accumulation_steps", 1) or 1))
+        self.stepper.accum = accum
         # trainer.py:445-450 update_config_params / update_train_steps: max_train_steps, or num_train_epochs full passes
         max_steps = _cfg(c, "training.max_train_steps")
         try:
-            per_epoch = len(self.train_dataloader)
+            per_epoch = -(-len(self.train_dataloader) // accum)          # num_update_steps_per_epoch
         except TypeError:
             per_epoch = None
         if max_steps is None:
@@ -551,6 +555,8 @@ class UnetFineTuner(Trainer):
                 rec = {"step": self.global_step, "finetuning/prediction_model_lr": lr}
                 keys = ("finetuning/loss", "finetuning/diffusion_loss", "finetuning/distillation_loss", "finetuning/block_loss")
                 vals = [torch.stack(loss)]
+                if accum != 1:
+                    vals[0] = vals[0] * torch.tensor([1.0 / accum, 1.0, 1.0, 1.0], device=vals[0].device, dtype=vals[0].dtype)
                 if upper_due:          # trainer.py:2795-2816
                     if ub is None:
                         try:
