@@ -300,7 +300,8 @@ class BilevelStepper:
         # Every role has ONE dedicated stream per process (k.role_stream): never a pooled torch stream, which would alias
         # another role after a few stepper instances.
         cuda = self.dev.type == "cuda"
-        self.teacher_stream = (k.role_stream(self.dev, "teacher")
+        t_hi = os.environ.get("PDMK_TEACHER_PRIO", "0") == "1"     # (A/B knob: the role streams are low-priority streams by default)
+        self.teacher_stream = (k.role_stream(self.dev, "teacher_hi" if t_hi else "teacher", high_priority=t_hi)
                                if cuda and os.environ.get("PDMK_TEACHER_STREAM", "1") != "0" else None)
         self.losses = torch.zeros(4, device=self.dev, dtype=torch.float64)   # diff, dist, block, (unused); zeroed by k.zero_
         # transposed (dgrad) weight copies are refreshed at the START of the next training step, beside its forward, instead
@@ -589,7 +590,8 @@ class GraphedBilevel:
         # AdamW of every finished share of the arena runs beside the rest of the backward (valid without gradient-norm
         # clipping, which needs all gradients first; the shipped configs do not clip: trainer.py:2784-2786)
         self.stream_opt = stream_opt and os.environ.get("PDMK_STREAM_OPT", "1") != "0"     # (0: A/B switch - AdamW after the backward)
-        self.opt_stream = k.role_stream(dev, "opt")
+        opt_hi = os.environ.get("PDMK_OPT_PRIO", "0") == "1"      # (A/B knob: the streamed AdamW on a high-priority stream)
+        self.opt_stream = k.role_stream(dev, "opt_hi" if opt_hi else "opt", high_priority=opt_hi)
         self.cap_stream = k.role_stream(dev, "capture")
         self.closed = False
         # Cross-step teacher prefetch (PDMK_TEACHER_PREFETCH=1, or prefetch=True): the frozen teacher's pass of the NEXT step in
