@@ -67,8 +67,9 @@ def run(mode, world, rank, out=None):
     store = student.store
     init = store.master.clone()
     graphs = None
-    if mode == "graph":
-        graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True)
+    prefetch = mode == "graph-prefetch"     # the teacher pass of the next step queued behind this step's loss heads, on every rank
+    if mode in ("graph", "graph-prefetch"):
+        graphs = GraphedBilevel(st, B, 4, 16, 16, 13, 64, segments=3, stream_opt=True, prefetch=prefetch)
         graphs.force_segments = True            # world 1 takes the multi-graph replay path too
         graphs.capture(bilevel=True)
         assert len(graphs.g_main.bwd) == 3 and graphs.g_main.teacher is not None      # fp32 engine: no lockstep
@@ -80,6 +81,7 @@ def run(mode, world, rank, out=None):
         scale = st._gscale
     else:
         graphs._load(d["lat"], d["noise"], d["t"], d["ehs"])
+        graphs._claim(False, None, (d["lat"], d["noise"], d["t"], d["ehs"]))      # (prefetch mode: the teacher graph's own inputs)
         graphs._replay_step(graphs.g_main, None)
         scale = 1.0 / world
     torch.cuda.synchronize()
@@ -94,11 +96,21 @@ def run(mode, world, rank, out=None):
             if it == UPPER_AT:
                 st.upper_step(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
                 st.optimizer_step(upper=True)
-        else:
+        elif not prefetch:
             graphs.main(d["lat"], d["noise"], d["t"], d["ehs"])
             if it == UPPER_AT:
                 graphs.upper(d["lat"], d["noise"], d["t"], d["ehs"], d["empty"])
+        else:
+            tup = lambda q: (q["lat"], q["noise"], q["t"], q["ehs"])
+            nxt = dict(next_batch=tup(data[it + 1]), next_id=it + 1) if it + 1 < ITERS else {}
+            if it == UPPER_AT:
+                graphs.main(*tup(d), batch_id=it, next_upper=tup(d) + (d["empty"],), upper_id=("u", it))
+                graphs.upper(*tup(d), d["empty"], batch_id=("u", it), **nxt)
+            else:
+                graphs.main(*tup(d), batch_id=it, **nxt)
     torch.cuda.synchronize()
+    if prefetch:
+        assert graphs.prefetch and graphs.prefetch_hits == ITERS, graphs.prefetch_hits      # main steps 1 .. ITERS - 1 and the upper step
     res = {"grad": grad, "master": store.master.cpu(), "init": init.cpu(), "lr": st.opt.current_lr()}
     if out and rank == 0:
         torch.save(res, out)
@@ -155,7 +167,7 @@ def run_comm(world, rank, out):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", required=True, choices=["eager", "graph", "comm"])
+    ap.add_argument("--mode", required=True, choices=["eager", "graph", "graph-prefetch", "comm"])
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])

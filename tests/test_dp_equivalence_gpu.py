@@ -45,7 +45,8 @@ def _spawn(mode, world, out, dp_mode="allreduce"):
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
 
 
-@pytest.mark.parametrize("mode,dp_mode", [("eager", "allreduce"), ("graph", "allreduce"), ("graph", "rs_ag")])
+@pytest.mark.parametrize("mode,dp_mode", [("eager", "allreduce"), ("graph", "allreduce"), ("graph", "rs_ag"),
+                                          ("graph-prefetch", "allreduce")])
 def test_two_ranks_equal_one_rank_with_twice_the_batch(dev, tmp_path, mode, dp_mode):
     """dp_mode rs_ag: every bucket as reduce-scatter + all-gather of `world` shares instead of one
     all-reduce - the same sums, so the same bounds."""

@@ -760,7 +760,8 @@ class GraphedBilevel:
     # ------------------------------------------------------------------ replay
     def _replay_step(self, cs, opt=None, have_teacher=False, ahead=None):
         """opt: the optimiser to apply (None = gradients only, the caller applies the optimiser).
-        have_teacher: the teacher graph of this step is already queued on the teacher stream (prefetched by the previous step).
+        have_teacher: the teacher graph of this step is already queued on the teacher stream (prefetched by the previous step);
+        in prefetch mode the caller has been through `_claim` (which loads the teacher graphs' own inputs when it returns False).
         ahead: callable that queues the teacher pass(es) of later steps; called once this step's loss heads are queued."""
         st = self.st
         store = st.student.store
