@@ -68,15 +68,15 @@ class UNetEngine:
         self.macs = 0
         self.count_macs = False
         self.grad_ready_cb = None      # called with an arena offset: every gradient at or beyond it is final
-        # weight-gradient GEMMs only feed the optimiser: they run on a side stream (a parallel branch of the captured
-        # graph) next to the dgrad chain, which is the critical path of the backward pass
         self.temb_lay, self.temb_cols = temb_layout(cfg, blocks)
         self.kv_lay, self.kv_cols = kv_layout(blocks)
         # skip k (push order) is concatenated behind an h of cat_ch[k] channels (None: its consumer ResBlock is dropped)
         ups = [r for b in blocks if b.kind == "up" for r in b.resnets]
         self.cat_ch = [None if r.dropped else padc(r.cin - r.skip) for r in reversed(ups)]
-        # (eager mode only, opt-in, measured slower once the ring kernels own the LDS: PDMK_WGRAD_ASYNC=1; never under
-        # stream capture - captured graphs are single-stream, bilevel.py GraphedBilevel)
+        # weight-gradient GEMMs only feed the optimiser, so they could run on a side stream next to the dgrad chain: eager mode
+        # only, opt-in (PDMK_WGRAD_ASYNC=1), measured slower since the ring kernels own the LDS (round 4, eager: 181.9 images/s in
+        # line and grouped, 177.1 in line one by one, 173.9 on the side stream); never under stream capture - captured graphs are
+        # single-stream (bilevel.py GraphedBilevel)
         self.wgrad_async = os.environ.get("PDMK_WGRAD_ASYNC", "0") == "1"
         self.wgrad_stream = None          # the dedicated "wgrad" role stream, created on first use
         self.fuse_geglu = os.environ.get("PDMK_FUSE_GEGLU", "1") != "0"     # A/B switch: 0 = projection + GEGLU as two passes
