@@ -347,9 +347,10 @@ def test_benchmarked_configuration_matches_oracle(dev, tmp_path):
     student, teacher = _models(torch.bfloat16, av)
     lat, noise, t, ehs, empty = (x.cuda() for x in _batch_inputs(B))
     st = BilevelStepper(student, teacher)
-    gr = GraphedBilevel(st, B, 4, 64, 64, 77, 1024)
+    gr = GraphedBilevel(st, B, 4, 64, 64, 77, 1024, prefetch=True)      # as bench.py builds it: cross-step teacher prefetch, 12 shares
     gr.capture(bilevel=True)
     assert len(gr.g_main.bwd) >= 2 and (gr.g_main.teacher is None) == st.lockstep
+    assert gr.prefetch != st.lockstep and (gr.g_main.loss is not None) == gr.prefetch
     # GroupNorm statistics from the producing GEMM's epilogue (pdmk_gemm_args.colstat): on unless PDMK_GN_EPI=0, and then the
     # path the captured step runs for most of its GroupNorms (the rest: split-K producers, copied concat halves)
     gc = student.engine.gn_count
@@ -357,10 +358,15 @@ def test_benchmarked_configuration_matches_oracle(dev, tmp_path):
     print("groupnorms per forward / with statistics from a GEMM epilogue:", gc)
     store = student.store
     # ---- main step: gradients only (no optimiser), replayed twice (the second replay must not see stale state)
-    for _ in range(2):
+    # (prefetch mode: the first replay runs its teacher pass in line and queues the SAME batch's pass - under the token "again" -
+    # and the upper step's behind its loss heads; the second replay and the upper step below find them done)
+    for i in range(2):
         k.zero_(store.grad)
         gr._load(lat, noise, t, ehs)
-        gr._replay_step(gr.g_main, None)
+        have = gr._claim(False, "again" if i else None, (lat, noise, t, ehs))
+        assert have == (bool(i) and gr.prefetch)
+        gr._replay_step(gr.g_main, None, have_teacher=have,
+                        ahead=gr._ahead_fn((lat, noise, t, ehs), "again", (lat, noise, t, ehs, empty), "up") if i == 0 else None)
     torch.cuda.synchronize()
     tot, d, s, b = st.total(st.losses)
     for name, got, ref in (("diff", d, diff), ("dist", s, dist_), ("block", b, block), ("total", tot, loss)):
@@ -370,7 +376,9 @@ def test_benchmarked_configuration_matches_oracle(dev, tmp_path):
     # ---- upper step
     k.zero_(store.grad)
     gr._load(lat, noise, t, ehs, empty)
-    gr._replay_step(gr.g_upper, None)
+    have = gr._claim(True, "up", (lat, noise, t, ehs, empty))
+    assert have == gr.prefetch
+    gr._replay_step(gr.g_upper, None, have_teacher=have)
     torch.cuda.synchronize()
     utot, _, us, _ = st.total(st.losses, upper=True)
     assert abs(utot - uloss) <= 3e-2 * abs(uloss) and abs(us - udist) <= 3e-2 * abs(udist), (utot, uloss, us, udist)
