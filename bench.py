@@ -304,6 +304,7 @@ def main():
         bilevel_iter(i, a.warmup)
     sync()
     el = time.perf_counter() - t0
+    hits_loop = graphs.prefetch_hits if graphs is not None else 0      # teacher passes handed over so far (warm-up + timed loop)
     if world > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -333,6 +334,9 @@ def main():
             extras["ms_upper_step_eager"] = round(timed(upper_iter, 2) * 1e3, 2)
         extras["launch_mode"] = "eager" if graphs is None else "hipGraph replay"
         extras["teacher_prefetch"] = prefetch_on     # GraphedBilevel: teacher pass of batch t+1 beside step t's backward
+        if prefetch_on:      # every main step but the very first, and every upper step, found its teacher pass queued
+            n_up = lambda n: sum(1 for i in range(n) if (i + 1) % a.upper_freq == 0)
+            extras["teacher_passes_handed_over"] = {"got": hits_loop, "steps": a.warmup + a.steps + n_up(a.warmup) + n_up(a.steps)}
         if graphs is not None:
             extras["graphs_per_main_step"] = len(graphs.g_main.all())
         extras["lockstep_forward"] = bool(st.lockstep)
