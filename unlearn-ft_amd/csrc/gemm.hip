@@ -1168,7 +1168,10 @@ extern "C" int pdmk_gemm_plan(const pdmk_gemm_args* a, pdmk_stream stream, int32
         if (id < 0) continue;
         g_plan_cfg[make_key(g, sk)] = id;
         plan_file_append('c', make_key(g, sk), id);
-        if (t < bt * (sk > 1 ? 0.97f : 1.0f)) { bt = t; best_sk = sk; }     // a split must win by > 3 %
+        // a split must win by > 3 % (PDMK_SPLIT_MARGIN=<percent>: A/B knob - in the step the finish pass carries bias / residual /
+        // statistics and runs from cold operands, which the back-to-back timing launches do not see)
+        static const float margin = getenv("PDMK_SPLIT_MARGIN") ? 1.0f - 0.01f * (float)atof(getenv("PDMK_SPLIT_MARGIN")) : 0.97f;
+        if (t < bt * (sk > 1 ? margin : 1.0f)) { bt = t; best_sk = sk; }
     }
     g_plan_sk[key0] = best_sk;
     plan_file_append('s', key0, best_sk);
