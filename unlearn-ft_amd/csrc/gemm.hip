@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -685,7 +686,7 @@ bool scratch_check() {
 
 // time `reps` launches of candidate `id` (plus, for split-K, the workspace clear and the finish pass) in microseconds
 float time_candidate(const pdmk_gemm_args& a, hipStream_t st, int id, float* ws, void* fin_out, hipEvent_t e0, hipEvent_t e1) {
-    const int reps = 3;
+    static const int reps = getenv("PDMK_TUNE_REPS") ? std::max(1, atoi(getenv("PDMK_TUNE_REPS"))) : 3;     // (A/B knob: 8 / 20 give the same step as 3)
     auto once = [&]() -> int {
         if (a.splitk > 1 && a.a_mode != PDMK_A_COLK) {    // slab split-K + the finish pass that adds the slabs
             const int rc = launch_candidate(a, st, id);
