@@ -33,3 +33,6 @@ for q, rs in sorted(by.items(), key=lambda kv: -len(kv[1])):
     print(f"stream {q}: {len(rs)} kernels, kernel time {sum(r[1]-r[0] for r in rs)/1e6:.2f} ms, {len(small)} gaps < 20 us summing "
           f"{sum(small)/1e6:.2f} ms (median {sorted(small)[len(small)//2]/1e3 if small else 0:.2f} us), "
           f"{len(gaps)-len(small)} longer gaps summing {sum(g for g in gaps if g >= 20000)/1e6:.2f} ms")
+    big = sorted(((b[0] - a[1], a[2], b[2]) for a, b in zip(rs, rs[1:]) if b[0] - a[1] >= 20000), reverse=True)[:6]
+    for gp, an, bn in big:
+        print(f"    gap {gp/1e3:8.1f} us  after {an[:60]:60s}  before {bn[:60]}")
