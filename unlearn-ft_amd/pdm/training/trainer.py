@@ -502,6 +502,14 @@ class UnetFineTuner(Trainer):
         # trainer.py:2744-2767: a resumed run starts at first_epoch = global_step // steps per epoch
         first_epoch = self.global_step // per_epoch if (per_epoch and self.global_step) else 0
         upper_iter = iter(self.upper_dataloader) if self.bilevel else None
+
+        def next_upper():            # sample a batch from the upper dataset, restarting it when it runs out (trainer.py:2798-2803)
+            nonlocal upper_iter
+            try:
+                return next(upper_iter)
+            except StopIteration:
+                upper_iter = iter(self.upper_dataloader)
+                return next(upper_iter)
         pending = None
         t0 = time.time()
         epoch = first_epoch
@@ -528,11 +536,7 @@ class UnetFineTuner(Trainer):
                     prepared = ahead[0] if (ahead is not None and ahead[1] == gs) else self._prepare(batch)
                     ahead, self._rng_snapshot = None, None
                     if upper_due:
-                        try:
-                            ub = next(upper_iter)
-                        except StopIteration:
-                            upper_iter = iter(self.upper_dataloader)
-                            ub = next(upper_iter)
+                        ub = next_upper()
                         up_prepared = self._prepare(ub, upper=True)
                     # no look-ahead into a step that will not run, across an epoch boundary, or past a point where something else
                     # draws from the generator / stores its state between the steps (validation, image logging)
@@ -559,11 +563,7 @@ class UnetFineTuner(Trainer):
                     vals[0] = vals[0] * torch.tensor([1.0 / accum, 1.0, 1.0, 1.0], device=vals[0].device, dtype=vals[0].dtype)
                 if upper_due:          # trainer.py:2795-2816
                     if ub is None:
-                        try:
-                            ub = next(upper_iter)
-                        except StopIteration:
-                            upper_iter = iter(self.upper_dataloader)
-                            ub = next(upper_iter)
+                        ub = next_upper()
                     up = (self.upper_step(ub, prepared=up_prepared, batch_id=("upper", self.global_step), **main_next)
                           if self.teacher_prefetch else self.upper_step(ub))
                     rec["finetuning/upper_prediction_model_lr"] = (
